@@ -1,0 +1,122 @@
+/*
+ * merizo_search_amd.h -- C ABI of the MI355X (gfx950) Foldclass embed-and-search library.
+ *
+ * The reference (psipred/merizo_search) has no FFI: its hot path is Python calling torch /
+ * faiss.  Each entry point below replaces one of those call sites; the citation names the
+ * reference lines whose arithmetic the entry point performs.  All pointers are DEVICE
+ * pointers owned by the caller unless a parameter says "host"; `stream` is a hipStream_t
+ * (0 = the null stream).  Functions are asynchronous on `stream`, never allocate, never
+ * synchronise.  Return 0 on success, a negative MS_ERR_* otherwise; ms_last_error() gives
+ * the message of the calling thread's last failure.  Embedding width is fixed at 128
+ * (FoldClassNet(128), reference programs/Foldclass/dbsearch.py:40).
+ *
+ * Paths below are relative to /root/reference/merizo_search/programs/Foldclass/.
+ */
+#ifndef MERIZO_SEARCH_AMD_H
+#define MERIZO_SEARCH_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MS_DIM 128
+#define MS_OK 0
+#define MS_ERR_ARG (-1)       /* bad argument (NULL pointer, k < 1, d != 128, ...) */
+#define MS_ERR_WORKSPACE (-2) /* workspace too small */
+#define MS_ERR_HIP (-3)       /* a HIP call / kernel launch failed */
+#define MS_ERR_RANGE (-4)     /* structure longer than the positional table, n >= 2^31, ... */
+
+typedef void *ms_stream_t;
+
+/* Library / device introspection. */
+int ms_version(void);
+const char *ms_last_error(void);
+int ms_device_count(void);
+int ms_device_cu_count(void);
+
+/* ------------------------------------------------------------------ search ---------- */
+
+/* Score semantics of ms_ip_topk. */
+#define MS_MODE_IP_PRENORM 0 /* faiss path: database rows and queries used as given (inner product);
+                                 knn_exact_faiss, dbsearch.py:213-248 */
+#define MS_MODE_COSINE_RAW 1 /* `.pt` path: F.cosine_similarity(db, q) * mask over a RAW database;
+                                 search_query_against_db, dbsearch.py:75-81 */
+
+/* F.normalize(x) in place: x[r,:] /= max(||x[r,:]||_2, eps).  dbsearch.py:303-304 (eps 1e-12);
+ * also the per-operand normalisation inside F.cosine_similarity (eps 1e-8), dbsearch.py:78. */
+int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stream);
+
+/* inv_norm[r] = 1 / max(||x[r,:]||_2, eps): the database half of F.cosine_similarity
+ * (dbsearch.py:78), computed once per database instead of once per query. */
+int ms_row_inv_norms(const float *x, int64_t n, int d, float eps, float *inv_norm, ms_stream_t stream);
+
+/* Bytes of scratch ms_ip_topk needs for a database shard of n rows, nq queries, top k. */
+size_t ms_ip_topk_workspace_bytes(int64_t n, int nq, int k);
+
+/* Exact top-k of nq queries against n database rows (row-major float32 [n,128], resident in HBM).
+ *   mode MS_MODE_IP_PRENORM: score = <db[r], q>; replaces IndexFlat.add/search + `I += i0`
+ *        for one block or shard (dbsearch.py:234-242).  inv_norm/lengths/qlen must be NULL.
+ *   mode MS_MODE_COSINE_RAW: score = cos(db[r], q) * mask, mask = (qlen[q] >= lengths[r]*mincov)
+ *        (dbsearch.py:76-79); masked rows score (+-)0.0 and stay candidates, as in the
+ *        reference.  q is raw (normalised internally, eps 1e-8); inv_norm = ms_row_inv_norms(db,
+ *        1e-8) or NULL (then computed into the workspace on every call, as the reference does).
+ *        lengths/qlen NULL = no mask.
+ * Output: out_scores float32 [nq,k], out_idx int64 [nq,k] = row_offset + row, sorted by score
+ * descending, ties by ascending row (torch.topk / faiss leave tie order unspecified).  If
+ * n < k the tail is (-inf, -1), like faiss.  Any k >= 1 is accepted (k > 64 costs
+ * ceil(k/64) scans).  n must be < 2^31. */
+int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+               const float *inv_norm, const float *lengths, const float *qlen, float mincov, float *out_scores,
+               int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream);
+
+/* The two stages of ms_ip_topk for k <= 64, exposed so that a profiler / bench can time the
+ * scan kernel alone: ms_ip_topk_scan runs the fused score + per-chunk top-k scan into the
+ * workspace, ms_ip_topk_finish merges the per-chunk lists into the outputs. */
+int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
+                    const float *lengths, const float *qlen, float mincov, void *workspace, size_t workspace_bytes,
+                    ms_stream_t stream);
+int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_scores, int64_t *out_idx,
+                      void *workspace, size_t workspace_bytes, ms_stream_t stream);
+
+/* Merge S sorted result lists per query into the best k: faiss.ResultHeap(nq,k).add_result /
+ * finalize (dbsearch.py:224,240,245) and the cross-shard merge after the RCCL all-gather.
+ * scores float32 [S,nq,k], idx int64 [S,nq,k] (idx < 0 = padding), each list sorted best-first. */
+int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k, float *out_scores,
+                  int64_t *out_idx, ms_stream_t stream);
+
+/* ------------------------------------------------------------------ encoder --------- */
+
+/* Floats in the canonical weight blob of the whole encoder (2 EGNN layers, state_dict order:
+ * edge_mlp.0.{weight,bias}, edge_mlp.2.{weight,bias}, edge_gate.0.{weight,bias},
+ * node_mlp.0.{weight,bias}, node_mlp.2.{weight,bias}; my_egnn_nocoords.py:18-34). */
+size_t ms_egnn_weight_floats(void);
+/* Bytes of the prepared (kernel-layout) weights produced by ms_egnn_prepare_weights. */
+size_t ms_egnn_prepared_bytes(void);
+/* Re-lay the canonical blob for the kernels (W1 split per node / distance column, W2 transposed
+ * in K-chunks, ...).  weights, prepared: device.  Replaces network_setup's load_state_dict +
+ * .to(device), dbsearch.py:35-45. */
+int ms_egnn_prepare_weights(const float *weights, void *prepared, ms_stream_t stream);
+
+/* Scratch bytes for embedding a ragged batch of nb structures with total_residues residues and
+ * sum_sq = sum over structures of N^2. */
+size_t ms_egnn_workspace_bytes(int nb, int64_t total_residues, int64_t sum_sq);
+
+/* FoldClassNet.forward for a ragged batch (nndef_fold_egnn_embed.py:50-62 with
+ * my_egnn_nocoords.py:44-74): node features = pe[:N] (the positional table is data,
+ * float32 [pe_len,128]), 2 EGNN layers over all N^2 residue pairs, mean over residues.
+ *   coords  float32 [total,3] CA coordinates, structures concatenated
+ *   offsets int32 [nb+1] (device), offsets[b]..offsets[b+1] = residues of structure b
+ *   offsets_host: the same array in host memory (used to size the launch; no device sync)
+ *   out     float32 [nb,128]
+ * Replaces network(x) at dbsearch.py:97-98, :299-301 and makedb.py:75-79 (there batch = 1). */
+int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float *coords, const int32_t *offsets,
+                  const int32_t *offsets_host, int nb, float *out, void *workspace, size_t workspace_bytes,
+                  ms_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MERIZO_SEARCH_AMD_H */

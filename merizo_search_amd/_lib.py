@@ -1,0 +1,113 @@
+"""ctypes binding of libmerizo_search_amd.so (C ABI: include/merizo_search_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or cannot be loaded every product
+entry point raises ``MerizoHipError``.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from typing import Optional
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmerizo_search_amd.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+MODE_IP_PRENORM = 0
+MODE_COSINE_RAW = 1
+DIM = 128
+
+
+class MerizoHipError(RuntimeError):
+    """The gfx950 library is unavailable or one of its entry points failed."""
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_int = ctypes.c_int
+_f = ctypes.c_float
+_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); exactly the symbols include/merizo_search_amd.h declares
+SIGNATURES = {
+    "ms_version": (_int, []),
+    "ms_last_error": (ctypes.c_char_p, []),
+    "ms_device_count": (_int, []),
+    "ms_device_cu_count": (_int, []),
+    "ms_l2_normalize_rows": (_int, [_vp, _i64, _int, _f, _vp]),
+    "ms_row_inv_norms": (_int, [_vp, _i64, _int, _f, _vp, _vp]),
+    "ms_ip_topk_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "ms_ip_topk": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "ms_egnn_weight_floats": (_sz, []),
+    "ms_egnn_prepared_bytes": (_sz, []),
+    "ms_egnn_prepare_weights": (_int, [_vp, _vp, _vp]),
+    "ms_egnn_workspace_bytes": (_sz, [_int, _i64, _i64]),
+    "ms_egnn_embed": (_int, [_vp, _vp, _int, _vp, _vp, _vp, _int, _vp, _vp, _sz, _vp]),
+}
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise MerizoHipError("hipcc build failed:\n" + proc.stdout + proc.stderr)
+    return LIB_PATH
+
+
+def load() -> ctypes.CDLL:
+    """Load the library and bind every declared symbol (no GPU needed for this step)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MerizoHipError(
+            f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "This package has no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the host
+        raise MerizoHipError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise MerizoHipError(f"{LIB_PATH} does not export {name}") from exc
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ms_last_error()
+        raise MerizoHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    """Return the torch module after verifying a HIP device and the library are present."""
+    import torch
+
+    lib = load()
+    if not torch.cuda.is_available() or lib.ms_device_count() < 1:
+        raise MerizoHipError("no MI355X / HIP device visible: the merizo_search_amd hot path runs on the GPU only "
+                             "(use the reference implementation for CPU runs)")
+    return torch
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (or None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,164 @@
+"""Tensor-level front end of the C ABI: torch tensors in, torch tensors out, HIP underneath.
+
+Every function runs on the tensors' device via libmerizo_search_amd.so on torch's current
+stream and raises ``MerizoHipError`` when the library or a GPU is missing (no fallback).
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import DIM, MODE_COSINE_RAW, MODE_IP_PRENORM, MerizoHipError, check, current_stream, ptr
+
+
+def _f32_cuda(t, name: str, cols: Optional[int] = None):
+    torch = _lib.require_gpu()
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise MerizoHipError(f"{name}: expected a CUDA/HIP tensor")
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise MerizoHipError(f"{name}: expected a contiguous float32 tensor")
+    if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
+        raise MerizoHipError(f"{name}: expected shape [n,{cols}], got {tuple(t.shape)}")
+    return t
+
+
+def l2_normalize_rows_(x, eps: float = 1e-12):
+    """In-place F.normalize(x) (reference dbsearch.py:303-304)."""
+    _f32_cuda(x, "x", DIM)
+    check(_lib.load().ms_l2_normalize_rows(ptr(x), x.shape[0], DIM, eps, current_stream()), "ms_l2_normalize_rows")
+    return x
+
+
+def row_inv_norms(x, eps: float = 1e-8):
+    """1 / max(||row||, eps) for every database row (the DB half of cosine_similarity)."""
+    torch = _lib.require_gpu()
+    _f32_cuda(x, "x", DIM)
+    inv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    check(_lib.load().ms_row_inv_norms(ptr(x), x.shape[0], DIM, eps, ptr(inv), current_stream()), "ms_row_inv_norms")
+    return inv
+
+
+class TopKWorkspace:
+    """Scratch buffer for ms_ip_topk, grown on demand and reused across calls."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, n: int, nq: int, k: int):
+        torch = _lib.require_gpu()
+        need = int(_lib.load().ms_ip_topk_workspace_bytes(n, nq, k))
+        if need == 0:
+            raise MerizoHipError(f"ms_ip_topk_workspace_bytes rejected n={n} nq={nq} k={k}")
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+def ip_topk(db, q, k: int, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
+            mincov: float = 0.0, row_offset: int = 0, workspace: Optional[TopKWorkspace] = None):
+    """Exact top-k of q [nq,128] against db [n,128] -> (scores f32 [nq,k], idx i64 [nq,k])."""
+    torch = _lib.require_gpu()
+    _f32_cuda(db, "db", DIM)
+    _f32_cuda(q, "q", DIM)
+    n, nq = db.shape[0], q.shape[0]
+    for name, t, size in (("inv_norm", inv_norm, n), ("lengths", lengths, n), ("qlen", qlen, nq)):
+        if t is not None:
+            _f32_cuda(t, name)
+            if t.numel() != size:
+                raise MerizoHipError(f"{name}: expected {size} elements, got {t.numel()}")
+    ws = (workspace or TopKWorkspace(db.device)).get(n, nq, k)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=db.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
+    check(_lib.load().ms_ip_topk(ptr(db), n, row_offset, ptr(q), nq, k, mode, ptr(inv_norm), ptr(lengths), ptr(qlen),
+                                 mincov, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), current_stream()), "ms_ip_topk")
+    return out_s, out_i
+
+
+def ip_topk_scan(db, q, k: int, ws, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
+                 mincov: float = 0.0):
+    """Stage 1 of ip_topk (k <= 64): the fused score + top-k scan kernel only (bench timing)."""
+    check(_lib.load().ms_ip_topk_scan(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
+                                      ptr(qlen), mincov, ptr(ws), ws.numel(), current_stream()), "ms_ip_topk_scan")
+
+
+def ip_topk_finish(n: int, nq: int, k: int, ws, out_s, out_i, row_offset: int = 0):
+    """Stage 2 of ip_topk (k <= 64): merge the per-chunk lists into the outputs."""
+    check(_lib.load().ms_ip_topk_finish(n, row_offset, nq, k, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(),
+                                        current_stream()), "ms_ip_topk_finish")
+
+
+def topk_merge(scores, idx):
+    """Merge [S,nq,k] sorted result lists (shards or blocks) into [nq,k]."""
+    torch = _lib.require_gpu()
+    if scores.dim() != 3 or idx.shape != scores.shape:
+        raise MerizoHipError("topk_merge: expected scores/idx of shape [S,nq,k]")
+    scores = scores.contiguous()
+    idx = idx.contiguous()
+    if scores.dtype != torch.float32 or idx.dtype != torch.int64 or not scores.is_cuda:
+        raise MerizoHipError("topk_merge: expected float32 / int64 CUDA tensors")
+    S, nq, k = scores.shape
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
+    check(_lib.load().ms_topk_merge(ptr(scores), ptr(idx), S, nq, k, ptr(out_s), ptr(out_i), current_stream()),
+          "ms_topk_merge")
+    return out_s, out_i
+
+
+class EgnnEncoder:
+    """The Foldclass structure encoder on one GPU: prepared weights + positional table.
+
+    ``embed(list of [N,3] arrays)`` -> float32 [B,128] tensor on the device.  Replaces
+    ``network(x)`` of the reference (dbsearch.py:97-98, :299-301; makedb.py:75-79) for a whole
+    ragged batch per launch.
+    """
+
+    def __init__(self, weights: np.ndarray, pe: np.ndarray, device="cuda:0"):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        self.device = torch.device(device)
+        nfl = int(lib.ms_egnn_weight_floats())
+        weights = np.ascontiguousarray(weights, dtype=np.float32).reshape(-1)
+        if weights.size != nfl:
+            raise MerizoHipError(f"encoder weights: expected {nfl} floats, got {weights.size}")
+        pe = np.ascontiguousarray(pe, dtype=np.float32).reshape(-1, DIM)
+        with torch.cuda.device(self.device):
+            w_dev = torch.from_numpy(weights).to(self.device)
+            self.pe = torch.from_numpy(pe).to(self.device)
+            self.prepared = torch.empty(int(lib.ms_egnn_prepared_bytes()), dtype=torch.uint8, device=self.device)
+            check(lib.ms_egnn_prepare_weights(ptr(w_dev), ptr(self.prepared), current_stream()),
+                  "ms_egnn_prepare_weights")
+            torch.cuda.current_stream().synchronize()
+        self.max_len = pe.shape[0]
+        self._ws = None
+
+    def embed(self, coords_list: Sequence[np.ndarray]):
+        torch = _lib.require_gpu()
+        lib = _lib.load()
+        nb = len(coords_list)
+        if nb == 0:
+            return torch.empty((0, DIM), dtype=torch.float32, device=self.device)
+        lens = np.array([int(np.asarray(c).shape[0]) for c in coords_list], dtype=np.int64)
+        if lens.min() < 1:
+            raise MerizoHipError("embed: empty structure")
+        if lens.max() > self.max_len:
+            raise MerizoHipError(f"embed: structure of {int(lens.max())} residues exceeds the positional table "
+                                 f"({self.max_len}); the reference fails here too (nndef_fold_egnn_embed.py:12)")
+        offsets = np.zeros(nb + 1, dtype=np.int32)
+        offsets[1:] = np.cumsum(lens)
+        flat = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, 3) for c in coords_list], axis=0)
+        with torch.cuda.device(self.device):
+            coords = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
+            offs_dev = torch.from_numpy(offsets).to(self.device)
+            need = int(lib.ms_egnn_workspace_bytes(nb, int(offsets[-1]), int((lens * lens).sum())))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            out = torch.empty((nb, DIM), dtype=torch.float32, device=self.device)
+            check(lib.ms_egnn_embed(ptr(self.prepared), ptr(self.pe), self.max_len, ptr(coords), ptr(offs_dev),
+                                    offsets.ctypes.data, nb, ptr(out), ptr(self._ws), self._ws.numel(),
+                                    current_stream()), "ms_egnn_embed")
+            # `offsets` (host) is only read during the call; coords/offs_dev stay alive until the
+            # stream has consumed them because torch's caching allocator is stream-ordered.
+        return out

@@ -1,10 +1,557 @@
-// placeholder until the encoder kernels land (next commit): keeps the ABI complete.
+// Foldclass structure encoder (2-layer EGNN, 128-d) on gfx950 for a ragged batch of CA traces.
+//
+// Reference arithmetic replaced (programs/Foldclass/):
+//   nndef_fold_egnn_embed.py:50-62  FoldClassNet.forward: pe[:N] -> 2 x EGNN -> mean over residues
+//   my_egnn_nocoords.py:44-74       EGNN.forward: all-pairs message / gate / aggregate / update
+//
+// The reference materialises edge_input [N,N,257] and the hidden layer [N,N,514].  Here the
+// first edge Linear is split per node (my_egnn_nocoords.py:58,63 restructured):
+//     W1 . [h_i, h_j, d2] + b1  =  (W1a . h_i + b1)  +  W1b . h_j  +  w_c * d2
+// so only the second edge Linear (514 -> 256, the dominant 2*514*256 FLOP per edge) runs over
+// the N^2 edges, as an fp32-MFMA GEMM whose A operand is produced on the fly:
+//
+//   ms_egnn_proj_kernel   Ap = h.W1a^T + b1, Bp = h.W1b^T           [nodes x 520], float4-transposed
+//   ms_egnn_edge_kernel   per tile of 128 consecutive edges (i*N + j) of one structure:
+//                           H = SiLU(Ap_i + Bp_j + w_c d2_ij)      VALU, staged through LDS
+//                           M = SiLU(H . W2^T + b2)                32x32x2 fp32 MFMA, K = 520
+//                           g = sigmoid(M . w_g + b_g); M *= g     in-register, per edge row
+//                           per-residue partial sums of M over the tile's rows -> records
+//   ms_egnn_node_kernel   m_i = sum of records; h' = Wn2.SiLU(Wn1.[h, m_i] + bn1) + bn2 + h
+//   ms_egnn_pool_kernel   mean over residues
+//
+// No atomics: every sum has a fixed order, results are bit-reproducible run to run.
 #include "ms_common.h"
-extern "C" {
-size_t ms_egnn_weight_floats(void) { return 2 * 396165; }
-size_t ms_egnn_prepared_bytes(void) { return 16; }
-int ms_egnn_prepare_weights(const float *, void *, ms_stream_t) { MS_FAIL(MS_ERR_ARG, "ms_egnn: not built yet"); }
-size_t ms_egnn_workspace_bytes(int, int64_t, int64_t) { return 16; }
-int ms_egnn_embed(const void *, const float *, int, const float *, const int32_t *, const int32_t *, int, float *,
-                  void *, size_t, ms_stream_t) { MS_FAIL(MS_ERR_ARG, "ms_egnn: not built yet"); }
+
+#include <math.h>
+
+namespace {
+
+constexpr int DIM = 128;
+constexpr int MD = 256;          // m_dim
+constexpr int EIN = 257;         // edge input width
+constexpr int EH = 514;          // edge hidden width
+constexpr int EHP = 520;         // padded to a multiple of 8 (zero weights in the pad)
+constexpr int KQ = EHP / 4;      // 130 float4 quads over the hidden width
+constexpr int NGRP = EHP / 8;    // 65 MFMA operand groups (8 k each: one float4 per lane half)
+constexpr int STAGE_G = 5;       // groups per pipeline stage
+constexpr int NSTAGE = NGRP / STAGE_G;   // 13
+constexpr int NIN = 384;
+constexpr int NHID = 256;
+constexpr int TILE_E = 128;      // edges per workgroup tile (4 waves x 32 rows)
+constexpr int NODES_PB = 16;     // nodes per workgroup in the node-level kernels
+constexpr int LAYER_FLOATS = 396165;
+
+// canonical blob offsets (state_dict order, see include/merizo_search_amd.h)
+constexpr int C_W1 = 0;
+constexpr int C_B1 = C_W1 + EH * EIN;
+constexpr int C_W2 = C_B1 + EH;
+constexpr int C_B2 = C_W2 + MD * EH;
+constexpr int C_WG = C_B2 + MD;
+constexpr int C_BG = C_WG + MD;
+constexpr int C_WN1 = C_BG + 1;
+constexpr int C_BN1 = C_WN1 + NHID * NIN;
+constexpr int C_WN2 = C_BN1 + NHID;
+constexpr int C_BN2 = C_WN2 + DIM * NHID;
+static_assert(C_BN2 + DIM == LAYER_FLOATS, "blob layout");
+
+// prepared (kernel-layout) per-layer offsets, in floats
+constexpr int P_W1AT = 0;                          // [128 k][520 c]
+constexpr int P_W1BT = P_W1AT + DIM * EHP;         // [128 k][520 c]
+constexpr int P_B1 = P_W1BT + DIM * EHP;           // [520]
+constexpr int P_WC = P_B1 + EHP;                   // [520]  distance column of W1
+constexpr int P_W2F = P_WC + EHP;                  // [65 g][8 nt][64 lanes][4]  MFMA B fragments
+constexpr int P_B2 = P_W2F + NGRP * 8 * 64 * 4;    // [256]
+constexpr int P_WG = P_B2 + MD;                    // [256]
+constexpr int P_BG = P_WG + MD;                    // [4] (1 used)
+constexpr int P_WN1T = P_BG + 4;                   // [384 k][256 o]
+constexpr int P_BN1 = P_WN1T + NIN * NHID;         // [256]
+constexpr int P_WN2T = P_BN1 + NHID;               // [256 k][128 o]
+constexpr int P_BN2 = P_WN2T + NHID * DIM;         // [128]
+constexpr int P_LAYER = P_BN2 + DIM;
+static_assert(P_LAYER % 4 == 0 && P_W2F % 4 == 0 && P_WC % 4 == 0 && P_B1 % 4 == 0, "float4 alignment");
+
+__device__ __forceinline__ float silu_f(float x) {
+    // x / (1 + exp(-x)); v_exp_f32 + v_rcp_f32 (about 1 ulp each)
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
 }
+__device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+
+// ---------------------------------------------------------------- weight preparation ---
+__global__ __launch_bounds__(256) void ms_egnn_prepare_kernel(const float *__restrict__ blob, float *__restrict__ prep) {
+    const int layer = blockIdx.y;
+    const float *w = blob + (size_t)layer * LAYER_FLOATS;
+    float *p = prep + (size_t)layer * P_LAYER;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P_LAYER; t += gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        if (t < P_W1BT) {                       // W1aT[k][c] = W1[c][k]
+            const int k = t / EHP, c = t % EHP;
+            if (c < EH) v = w[C_W1 + c * EIN + k];
+        } else if (t < P_B1) {                  // W1bT[k][c] = W1[c][128 + k]
+            const int u = t - P_W1BT, k = u / EHP, c = u % EHP;
+            if (c < EH) v = w[C_W1 + c * EIN + DIM + k];
+        } else if (t < P_WC) {
+            const int c = t - P_B1;
+            if (c < EH) v = w[C_B1 + c];
+        } else if (t < P_W2F) {
+            const int c = t - P_WC;
+            if (c < EH) v = w[C_W1 + c * EIN + 2 * DIM];
+        } else if (t < P_B2) {                  // W2f[g][nt][kh*32+n][u] = W2[32nt+n][8g+4kh+u]
+            const int u4 = t - P_W2F;
+            const int u = u4 & 3, lane = (u4 >> 2) & 63, nt = (u4 >> 8) & 7, g = u4 >> 11;
+            const int k = 8 * g + 4 * (lane >> 5) + u, n = 32 * nt + (lane & 31);
+            if (k < EH) v = w[C_W2 + n * EH + k];
+        } else if (t < P_WG) {
+            v = w[C_B2 + (t - P_B2)];
+        } else if (t < P_BG) {
+            v = w[C_WG + (t - P_WG)];
+        } else if (t < P_WN1T) {
+            if (t == P_BG) v = w[C_BG];
+        } else if (t < P_BN1) {                 // Wn1T[k][o] = Wn1[o][k]
+            const int u = t - P_WN1T, k = u / NHID, o = u % NHID;
+            v = w[C_WN1 + o * NIN + k];
+        } else if (t < P_WN2T) {
+            v = w[C_BN1 + (t - P_BN1)];
+        } else if (t < P_BN2) {                 // Wn2T[k][o] = Wn2[o][k]
+            const int u = t - P_WN2T, k = u / DIM, o = u % DIM;
+            v = w[C_WN2 + o * NHID + k];
+        } else {
+            v = w[C_BN2 + (t - P_BN2)];
+        }
+        p[t] = v;
+    }
+}
+
+// ---------------------------------------------------------------- batch plan -----------
+// Per structure d: n, C = ceil(n/32)+1 (records per residue), exclusive prefixes of edge
+// tiles and of records.  One workgroup, blocked scan.
+__global__ __launch_bounds__(1024) void ms_egnn_plan_kernel(const int32_t *__restrict__ offsets, int nb,
+                                                           int32_t *__restrict__ tile_pre, int32_t *__restrict__ rec_pre) {
+    __shared__ int64_t s_t[1024];
+    __shared__ int64_t s_r[1024];
+    const int tid = threadIdx.x;
+    const int per = (nb + 1023) / 1024;
+    const int d0 = tid * per, d1 = (d0 + per < nb) ? d0 + per : nb;
+    int64_t st = 0, sr = 0;
+    for (int d = d0; d < d1; ++d) {
+        const int64_t n = offsets[d + 1] - offsets[d];
+        st += (n * n + TILE_E - 1) / TILE_E;
+        sr += n * ((n + 31) / 32 + 1);
+    }
+    s_t[tid] = st; s_r[tid] = sr;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int64_t a = 0, b = 0;
+        if (tid >= off) { a = s_t[tid - off]; b = s_r[tid - off]; }
+        __syncthreads();
+        s_t[tid] += a; s_r[tid] += b;
+        __syncthreads();
+    }
+    int64_t pt = s_t[tid] - st, pr = s_r[tid] - sr;   // exclusive
+    for (int d = d0; d < d1; ++d) {
+        const int64_t n = offsets[d + 1] - offsets[d];
+        tile_pre[d] = (int32_t)pt; rec_pre[d] = (int32_t)pr;
+        pt += (n * n + TILE_E - 1) / TILE_E;
+        pr += n * ((n + 31) / 32 + 1);
+    }
+    if (tid == 1023) { tile_pre[nb] = (int32_t)s_t[1023]; rec_pre[nb] = (int32_t)s_r[1023]; }
+}
+
+__device__ __forceinline__ int find_segment(const int32_t *__restrict__ pre, int n, int x) {
+    // largest d in [0, n) with pre[d] <= x  (pre is non-decreasing, pre[0] = 0)
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (pre[mid] <= x) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// node -> structure, and h0 = pe[position in structure]  (nndef_fold_egnn_embed.py:27-30,54)
+__global__ __launch_bounds__(256) void ms_egnn_init_nodes_kernel(const int32_t *__restrict__ offsets, int nb, int total,
+                                                                 const float *__restrict__ pe,
+                                                                 int32_t *__restrict__ node_dom, float *__restrict__ h0) {
+    const int g = blockIdx.x * 8 + (threadIdx.x >> 5);    // 32 threads (one float4 each) per node
+    if (g >= total) return;
+    const int d = find_segment(offsets, nb, g);
+    const int pos = g - offsets[d];
+    const int c4 = threadIdx.x & 31;
+    if (c4 == 0) node_dom[g] = d;
+    reinterpret_cast<f32x4 *>(h0 + (size_t)g * DIM)[c4] = reinterpret_cast<const f32x4 *>(pe + (size_t)pos * DIM)[c4];
+}
+
+// ---------------------------------------------------------------- node projections -----
+// ApT4[kq][g] (float4) = b1[4kq..] + sum_k h[g][k] W1[4kq..][k];  BpT4 likewise with W1[:,128+k], no bias.
+__global__ __launch_bounds__(256) void ms_egnn_proj_kernel(const float *__restrict__ prep, const float *__restrict__ h,
+                                                          int total, f32x4 *__restrict__ ApT4, f32x4 *__restrict__ BpT4) {
+    __shared__ float hs[NODES_PB][DIM + 1];
+    const int g0 = blockIdx.x * NODES_PB;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NODES_PB * DIM; e += 256) {
+        const int n = e >> 7, k = e & 127;
+        hs[n][k] = (g0 + n < total) ? h[(size_t)(g0 + n) * DIM + k] : 0.0f;
+    }
+    __syncthreads();
+    const int n = tid & 15, cq0 = tid >> 4;
+    const bool valid = g0 + n < total;
+    const f32x4 *w1a = reinterpret_cast<const f32x4 *>(prep + P_W1AT);
+    const f32x4 *w1b = reinterpret_cast<const f32x4 *>(prep + P_W1BT);
+    const f32x4 *b1 = reinterpret_cast<const f32x4 *>(prep + P_B1);
+    for (int cq = cq0; cq < KQ; cq += 16) {
+        f32x4 a = b1[cq];
+        f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int k = 0; k < DIM; ++k) {
+            const float x = hs[n][k];
+            const f32x4 wa = w1a[k * KQ + cq], wb = w1b[k * KQ + cq];
+            a.x = fmaf(x, wa.x, a.x); a.y = fmaf(x, wa.y, a.y); a.z = fmaf(x, wa.z, a.z); a.w = fmaf(x, wa.w, a.w);
+            b.x = fmaf(x, wb.x, b.x); b.y = fmaf(x, wb.y, b.y); b.z = fmaf(x, wb.z, b.z); b.w = fmaf(x, wb.w, b.w);
+        }
+        if (valid) {
+            ApT4[(size_t)cq * total + g0 + n] = a;
+            BpT4[(size_t)cq * total + g0 + n] = b;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fused edge kernel ----
+struct EdgeParams {
+    const float *prep;            // this layer's prepared weights
+    const float *coords;          // [total,3]
+    const int32_t *offsets;       // [nb+1]
+    const int32_t *tile_pre;      // [nb+1]
+    const int32_t *rec_pre;       // [nb+1]
+    const f32x4 *ApT4;            // [130][total]
+    const f32x4 *BpT4;
+    float *part;                  // [records][256]
+    int nb;
+    int total;
+};
+
+__global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    f32x4 *Hl = reinterpret_cast<f32x4 *>(smem);                    // [5 g][4 m][64 lanes]
+    f32x4 *Wl = Hl + STAGE_G * 4 * 64;                              // [5 g][8 nt][64 lanes]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int T = blockIdx.x;
+    const int d = find_segment(p.tile_pre, p.nb, T);
+    const int off = p.offsets[d];
+    const int n = p.offsets[d + 1] - off;
+    const int tt = T - p.tile_pre[d];
+    const int64_t nn = (int64_t)n * n;
+    const int64_t e0 = (int64_t)tt * TILE_E;
+
+    // this thread's edge row (two threads per row, one per lane half of the A fragment)
+    const int R = tid & 127, kh = tid >> 7;
+    const int64_t e = e0 + R;
+    int i = 0, j = 0;
+    if (e < nn) { i = (int)(e / n); j = (int)(e - (int64_t)i * n); }
+    const int gi = off + i, gj = off + j;
+    float d2;
+    {
+        // rel_coors, dist = norm(rel), then dist * dist: my_egnn_nocoords.py:48-49,58
+        const float dx = p.coords[3 * gi] - p.coords[3 * gj];
+        const float dy = p.coords[3 * gi + 1] - p.coords[3 * gj + 1];
+        const float dz = p.coords[3 * gi + 2] - p.coords[3 * gj + 2];
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        d2 = dist * dist;
+    }
+    const f32x4 *wc4 = reinterpret_cast<const f32x4 *>(p.prep + P_WC);
+    const f32x4 *w2f = reinterpret_cast<const f32x4 *>(p.prep + P_W2F);
+
+    f32x4 pa[STAGE_G], pb[STAGE_G], pw[2 * STAGE_G];
+    auto issue_loads = [&](int s) {
+#pragma unroll
+        for (int g = 0; g < STAGE_G; ++g) {
+            const int kq = 2 * (STAGE_G * s + g) + kh;
+            pa[g] = p.ApT4[(size_t)kq * p.total + gi];
+            pb[g] = p.BpT4[(size_t)kq * p.total + gj];
+        }
+#pragma unroll
+        for (int it = 0; it < 2 * STAGE_G; ++it) pw[it] = w2f[(size_t)s * (STAGE_G * 8 * 64) + it * 256 + tid];
+    };
+    issue_loads(0);
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+    for (int s = 0; s < NSTAGE; ++s) {
+        // H = SiLU(Ap_i + Bp_j + w_c * d2), written straight into A-fragment order
+#pragma unroll
+        for (int g = 0; g < STAGE_G; ++g) {
+            const f32x4 wc = wc4[2 * (STAGE_G * s + g) + kh];
+            f32x4 hv;
+            hv.x = silu_f(fmaf(wc.x, d2, pa[g].x + pb[g].x));
+            hv.y = silu_f(fmaf(wc.y, d2, pa[g].y + pb[g].y));
+            hv.z = silu_f(fmaf(wc.z, d2, pa[g].z + pb[g].z));
+            hv.w = silu_f(fmaf(wc.w, d2, pa[g].w + pb[g].w));
+            Hl[(g * 4 + (R >> 5)) * 64 + kh * 32 + (R & 31)] = hv;
+        }
+#pragma unroll
+        for (int it = 0; it < 2 * STAGE_G; ++it) Wl[it * 256 + tid] = pw[it];
+        __syncthreads();
+        if (s + 1 < NSTAGE) issue_loads(s + 1);
+#pragma unroll
+        for (int g = 0; g < STAGE_G; ++g) {
+            const f32x4 a = Hl[(g * 4 + wave) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const f32x4 b = Wl[(g * 8 + nt) * 64 + lane];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue.  acc[nt][r]: edge row (r&3) + 8(r>>2) + 4(lane>>5) of this wave's 32 rows,
+    //      channel 32 nt + (lane & 31).
+    const int c = lane & 31, hh = lane >> 5;
+    float gate_dot[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gate_dot[r] = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const float b2 = p.prep[P_B2 + 32 * nt + c];
+        const float wg = p.prep[P_WG + 32 * nt + c];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float m = silu_f(acc[nt][r] + b2);          // edge_mlp[2] bias + SiLU (:21-22)
+            acc[nt][r] = m;
+            gate_dot[r] = fmaf(wg, m, gate_dot[r]);
+        }
+    }
+    const float bg = p.prep[P_BG];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float v = gate_dot[r];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        gate_dot[r] = sigmoid_f(v + bg);                      // edge_gate (:25-28)
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] *= gate_dot[r];   // m_ij * gate (:64)
+
+    // per-residue partial sums over this wave's 32 consecutive edges (m_i = sum_j m_ij, :69)
+    const int64_t u0 = e0 + 32 * wave;                 // first edge of the unit
+    if (u0 < nn) {
+        const int unit = tt * 4 + wave;                // 32-edge unit index inside the structure
+        const int C = (n + 31) / 32 + 1;
+        const int i_first = (int)(u0 / n);
+        int64_t last_e = u0 + 31;
+        if (last_e > nn - 1) last_e = nn - 1;
+        const int i_last = (int)(last_e / n);
+        for (int is = i_first; is <= i_last; ++is) {
+            const int64_t lo64 = (int64_t)is * n - u0, hi64 = (int64_t)(is + 1) * n - u0;
+            const int lo = lo64 < 0 ? 0 : (int)lo64;
+            const int hi = hi64 > 32 ? 32 : (int)hi64;
+            const int q = unit - (int)(((int64_t)is * n) >> 5);
+            float *dst = p.part + ((size_t)p.rec_pre[d] + (size_t)is * C + q) * MD;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    sum += (row >= lo && row < hi) ? acc[nt][r] : 0.0f;
+                }
+                sum += __shfl_xor(sum, 32);
+                if (hh == 0) dst[32 * nt + c] = sum;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- node update ----------
+struct NodeParams {
+    const float *prep;
+    const float *h_in;            // [total,128]
+    const float *part;            // [records][256]
+    const int32_t *offsets;
+    const int32_t *rec_pre;
+    const int32_t *node_dom;
+    float *h_out;                 // [total,128]
+    int total;
+};
+
+__global__ __launch_bounds__(256) void ms_egnn_node_kernel(const NodeParams p) {
+    __shared__ float xs[NODES_PB][NIN];      // [h, m_i]
+    __shared__ float hid[NODES_PB][NHID];
+    const int tid = threadIdx.x;
+    const int g0 = blockIdx.x * NODES_PB;
+    for (int e = tid; e < NODES_PB * DIM; e += 256) {
+        const int nd = e >> 7, k = e & 127;
+        xs[nd][k] = (g0 + nd < p.total) ? p.h_in[(size_t)(g0 + nd) * DIM + k] : 0.0f;
+    }
+    // m_i: sum this residue's records in record order
+    for (int nd = 0; nd < NODES_PB; ++nd) {
+        float m = 0.0f;
+        const int g = g0 + nd;
+        if (g < p.total) {
+            const int d = p.node_dom[g];
+            const int off = p.offsets[d];
+            const int n = p.offsets[d + 1] - off;
+            const int i = g - off;
+            const int C = (n + 31) / 32 + 1;
+            const int first = (int)(((int64_t)i * n) >> 5);
+            const int last = (int)(((int64_t)i * n + n - 1) >> 5);
+            const float *src = p.part + ((size_t)p.rec_pre[d] + (size_t)i * C) * MD + tid;
+            for (int q = 0; q <= last - first; ++q) m += src[(size_t)q * MD];
+        }
+        xs[nd][DIM + tid] = m;
+    }
+    __syncthreads();
+    {   // node_mlp[0] + SiLU (:31-32): thread = output channel, all 16 nodes
+        float a[NODES_PB];
+        const float b = p.prep[P_BN1 + tid];
+#pragma unroll
+        for (int nd = 0; nd < NODES_PB; ++nd) a[nd] = b;
+        const float *w = p.prep + P_WN1T + tid;
+#pragma unroll 4
+        for (int k = 0; k < NIN; ++k) {
+            const float wk = w[(size_t)k * NHID];
+#pragma unroll
+            for (int nd = 0; nd < NODES_PB; ++nd) a[nd] = fmaf(wk, xs[nd][k], a[nd]);
+        }
+#pragma unroll
+        for (int nd = 0; nd < NODES_PB; ++nd) hid[nd][tid] = silu_f(a[nd]);
+    }
+    __syncthreads();
+    {   // node_mlp[2] + residual (:33, :72): thread = (output channel, half of the nodes)
+        const int o = tid & 127, half = tid >> 7;
+        float a[NODES_PB / 2];
+        const float b = p.prep[P_BN2 + o];
+#pragma unroll
+        for (int nd = 0; nd < NODES_PB / 2; ++nd) a[nd] = b;
+        const float *w = p.prep + P_WN2T + o;
+#pragma unroll 4
+        for (int k = 0; k < NHID; ++k) {
+            const float wk = w[(size_t)k * DIM];
+#pragma unroll
+            for (int nd = 0; nd < NODES_PB / 2; ++nd) a[nd] = fmaf(wk, hid[half * (NODES_PB / 2) + nd][k], a[nd]);
+        }
+#pragma unroll
+        for (int nd = 0; nd < NODES_PB / 2; ++nd) {
+            const int node = half * (NODES_PB / 2) + nd;
+            if (g0 + node < p.total) p.h_out[(size_t)(g0 + node) * DIM + o] = a[nd] + xs[node][o];
+        }
+    }
+}
+
+// embed = mean over residues, in residue order (nndef_fold_egnn_embed.py:61)
+__global__ __launch_bounds__(128) void ms_egnn_pool_kernel(const float *__restrict__ h, const int32_t *__restrict__ offsets,
+                                                          float *__restrict__ out) {
+    const int d = blockIdx.x, c = threadIdx.x;
+    const int off = offsets[d], n = offsets[d + 1] - off;
+    float s = 0.0f;
+    for (int i = 0; i < n; ++i) s += h[(size_t)(off + i) * DIM + c];
+    out[(size_t)d * DIM + c] = s / (float)n;
+}
+
+struct EgnnCarve {
+    size_t off_h0, off_h1, off_ap, off_bp, off_part, off_tile_pre, off_rec_pre, off_node_dom, total;
+};
+
+EgnnCarve egnn_carve(int nb, int64_t total, int64_t rec_bound) {
+    EgnnCarve c;
+    size_t o = 0;
+    c.off_h0 = o; o += ms_align_up((size_t)total * DIM * sizeof(float), 256);
+    c.off_h1 = o; o += ms_align_up((size_t)total * DIM * sizeof(float), 256);
+    c.off_ap = o; o += ms_align_up((size_t)KQ * total * sizeof(f32x4), 256);
+    c.off_bp = o; o += ms_align_up((size_t)KQ * total * sizeof(f32x4), 256);
+    c.off_part = o; o += ms_align_up((size_t)rec_bound * MD * sizeof(float), 256);
+    c.off_tile_pre = o; o += ms_align_up((size_t)(nb + 1) * sizeof(int32_t), 256);
+    c.off_rec_pre = o; o += ms_align_up((size_t)(nb + 1) * sizeof(int32_t), 256);
+    c.off_node_dom = o; o += ms_align_up((size_t)total * sizeof(int32_t), 256);
+    c.total = o;
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ms_egnn_weight_floats(void) { return 2 * (size_t)LAYER_FLOATS; }
+size_t ms_egnn_prepared_bytes(void) { return 2 * (size_t)P_LAYER * sizeof(float); }
+
+int ms_egnn_prepare_weights(const float *weights, void *prepared, ms_stream_t stream) {
+    if (weights == nullptr || prepared == nullptr) MS_FAIL(MS_ERR_ARG, "ms_egnn_prepare_weights: NULL argument");
+    hipLaunchKernelGGL(ms_egnn_prepare_kernel, dim3(256, 2), dim3(256), 0, (hipStream_t)stream, weights, (float *)prepared);
+    MS_LAUNCH_CHECK("ms_egnn_prepare_kernel");
+    return MS_OK;
+}
+
+size_t ms_egnn_workspace_bytes(int nb, int64_t total_residues, int64_t sum_sq) {
+    if (nb < 1 || total_residues < 1 || sum_sq < 1) return 0;
+    // records per structure = N * (ceil(N/32) + 1) <= N^2/32 + 2N
+    return egnn_carve(nb, total_residues, sum_sq / 32 + 2 * total_residues + 1).total;
+}
+
+int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float *coords, const int32_t *offsets,
+                  const int32_t *offsets_host, int nb, float *out, void *workspace, size_t workspace_bytes,
+                  ms_stream_t stream) {
+    if (!prepared || !pe || !coords || !offsets || !offsets_host || !out || nb < 1)
+        MS_FAIL(MS_ERR_ARG, "ms_egnn_embed: NULL argument or nb < 1");
+    if (offsets_host[0] != 0) MS_FAIL(MS_ERR_ARG, "ms_egnn_embed: offsets[0] must be 0");
+    int64_t total = 0, sum_sq = 0, tiles = 0, recs = 0;
+    for (int d = 0; d < nb; ++d) {
+        const int64_t n = (int64_t)offsets_host[d + 1] - offsets_host[d];
+        if (n < 1) MS_FAIL(MS_ERR_ARG, "ms_egnn_embed: structure %d is empty", d);
+        if (n > pe_len)
+            MS_FAIL(MS_ERR_RANGE, "ms_egnn_embed: structure %d has %lld residues, positional table has %d", d, (long long)n, pe_len);
+        total += n; sum_sq += n * n;
+        tiles += (n * n + TILE_E - 1) / TILE_E;
+        recs += n * ((n + 31) / 32 + 1);
+    }
+    if (tiles >= 0x7FFFFFFF || recs >= 0x7FFFFFFF || total >= 0x7FFFFFFF)
+        MS_FAIL(MS_ERR_RANGE, "ms_egnn_embed: batch too large (sum N^2 = %lld); split it", (long long)sum_sq);
+    const EgnnCarve cv = egnn_carve(nb, total, sum_sq / 32 + 2 * total + 1);
+    if (workspace == nullptr || workspace_bytes < cv.total)
+        MS_FAIL(MS_ERR_WORKSPACE, "ms_egnn_embed: workspace %zu < %zu bytes", workspace_bytes, cv.total);
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *h0 = (float *)(ws + cv.off_h0), *h1 = (float *)(ws + cv.off_h1);
+    f32x4 *ap = (f32x4 *)(ws + cv.off_ap), *bp = (f32x4 *)(ws + cv.off_bp);
+    float *part = (float *)(ws + cv.off_part);
+    int32_t *tile_pre = (int32_t *)(ws + cv.off_tile_pre), *rec_pre = (int32_t *)(ws + cv.off_rec_pre);
+    int32_t *node_dom = (int32_t *)(ws + cv.off_node_dom);
+    const float *prep = (const float *)prepared;
+
+    hipLaunchKernelGGL(ms_egnn_plan_kernel, dim3(1), dim3(1024), 0, st, offsets, nb, tile_pre, rec_pre);
+    MS_LAUNCH_CHECK("ms_egnn_plan_kernel");
+    hipLaunchKernelGGL(ms_egnn_init_nodes_kernel, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, st, offsets, nb,
+                       (int)total, pe, node_dom, h0);
+    MS_LAUNCH_CHECK("ms_egnn_init_nodes_kernel");
+    const size_t edge_lds = (size_t)(STAGE_G * 4 * 64 + STAGE_G * 8 * 64) * sizeof(f32x4);
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
+    const unsigned node_blocks = (unsigned)((total + NODES_PB - 1) / NODES_PB);
+    float *hin = h0, *hout = h1;
+    for (int layer = 0; layer < 2; ++layer) {
+        const float *lp = prep + (size_t)layer * P_LAYER;
+        hipLaunchKernelGGL(ms_egnn_proj_kernel, dim3(node_blocks), dim3(256), 0, st, lp, hin, (int)total, ap, bp);
+        MS_LAUNCH_CHECK("ms_egnn_proj_kernel");
+        EdgeParams ep;
+        ep.prep = lp; ep.coords = coords; ep.offsets = offsets; ep.tile_pre = tile_pre; ep.rec_pre = rec_pre;
+        ep.ApT4 = ap; ep.BpT4 = bp; ep.part = part; ep.nb = nb; ep.total = (int)total;
+        hipLaunchKernelGGL(ms_egnn_edge_kernel, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
+        MS_LAUNCH_CHECK("ms_egnn_edge_kernel");
+        NodeParams np;
+        np.prep = lp; np.h_in = hin; np.part = part; np.offsets = offsets; np.rec_pre = rec_pre; np.node_dom = node_dom;
+        np.h_out = hout; np.total = (int)total;
+        hipLaunchKernelGGL(ms_egnn_node_kernel, dim3(node_blocks), dim3(256), 0, st, np);
+        MS_LAUNCH_CHECK("ms_egnn_node_kernel");
+        float *t = hin; hin = hout; hout = t;
+    }
+    hipLaunchKernelGGL(ms_egnn_pool_kernel, dim3(nb), dim3(128), 0, st, hin, offsets, out);
+    MS_LAUNCH_CHECK("ms_egnn_pool_kernel");
+    return MS_OK;
+}
+
+}  // extern "C"

@@ -1,6 +1,8 @@
 """GPU parity of the HIP search path (through the C ABI) against the CPU oracle and the
 reference goldens.  Integer work (indices) is bit-exact; scores are bit-exact in
-IP mode (the oracle restates the kernel's k order) and within 3e-7 in cosine mode."""
+IP mode (the oracle restates the kernel's k order).  In cosine mode the kernel scales the raw
+dot product by 1/||row|| where the reference normalises the row first, so scores agree to
+rounding only: COS_TOL = 2e-6 (north_star allows 1e-5)."""
 import os
 
 import numpy as np
@@ -9,6 +11,7 @@ import pytest
 from conftest import assert_topk_equivalent
 
 pytestmark = pytest.mark.gpu
+COS_TOL = 2e-6
 
 
 @pytest.fixture(scope="module")
@@ -105,7 +108,7 @@ def test_cosine_mask_topk_matches_reference_goldens(mincov, k, torch_gpu, golden
     inv = ops.row_inv_norms(d_db)
     s, i = ops.ip_topk(d_db, _dev(torch, q), k, mode=ops.MODE_COSINE_RAW, inv_norm=inv,
                        lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=mincov)
-    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), g[f"s_cov{mincov}_k{k}"], g[f"i_cov{mincov}_k{k}"], tol=3e-7)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), g[f"s_cov{mincov}_k{k}"], g[f"i_cov{mincov}_k{k}"], tol=COS_TOL)
     # inverse norms computed inside the call (as the reference does per query) give the same answer
     s2, i2 = ops.ip_topk(d_db, _dev(torch, q), k, mode=ops.MODE_COSINE_RAW, lengths=_dev(torch, lengths),
                          qlen=_dev(torch, qlen), mincov=mincov)
@@ -132,7 +135,7 @@ def test_cosine_all_masked_and_k_equals_ndb(torch_gpu, golden_dir):
     ql = np.array([200.0], np.float32)
     s, i = ops.ip_topk(_dev(torch, db2), _dev(torch, q[1:2]), 50, mode=ops.MODE_COSINE_RAW,
                        lengths=_dev(torch, len2), qlen=_dev(torch, ql), mincov=0.7)
-    assert_topk_equivalent(s.cpu().numpy()[0], i.cpu().numpy()[0], g["s_kfull"], g["i_kfull"], tol=3e-7)
+    assert_topk_equivalent(s.cpu().numpy()[0], i.cpu().numpy()[0], g["s_kfull"], g["i_kfull"], tol=COS_TOL)
 
 
 def test_cosine_vs_oracle_larger(torch_gpu):
@@ -145,7 +148,7 @@ def test_cosine_vs_oracle_larger(torch_gpu):
     s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), 10, mode=ops.MODE_COSINE_RAW,
                        lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
     s_ref, i_ref = orc.cosine_topk(db, q, 10, lengths, qlen, 0.7)
-    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=3e-7)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
 
 
 def test_normalize_rows_matches_reference_golden(torch_gpu, golden_dir):

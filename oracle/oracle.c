@@ -19,6 +19,7 @@
  * Tie policy (torch.topk / faiss heaps leave it implementation-defined): score descending,
  * then index ascending; -0.0 == +0.0.
  */
+#include <immintrin.h>
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -49,6 +50,13 @@
 #define ORC_LAYER_FLOATS (OFF_BN2 + ORC_DIM) /* 396165; x2 layers = 792330 parameters */
 
 int orc_layer_floats(void) { return ORC_LAYER_FLOATS; }
+
+#ifdef _OPENMP
+#include <omp.h>
+int orc_num_threads(void) { return omp_get_max_threads(); }
+#else
+int orc_num_threads(void) { return 1; }
+#endif
 
 static inline float silu_f(float x) { return x / (1.0f + expf(-x)); }     /* nn.SiLU */
 static inline float sigmoid_f(float x) { return 1.0f / (1.0f + expf(-x)); } /* nn.Sigmoid */
@@ -250,19 +258,69 @@ int orc_cosine_topk(const float *db, int64_t n, int d, int64_t row_offset, const
 /* One block of knn_exact_faiss, dbsearch.py:234-242: IndexFlat(d, METRIC_INNER_PRODUCT)
  * .add(block) / .search(xq, k) and `I += i0`.  xq and the block are used as given (the
  * reference passes F.normalize'd queries and a pre-normalised *_norm.db memmap).
- * If the block has fewer than k rows the tail is (-inf, -1) like faiss. */
+ * If the block has fewer than k rows the tail is (-inf, -1) like faiss.
+ *
+ * Every (row, query) score is exactly dot_ordered(): one fmaf chain in the chosen k order.
+ * For speed (this is also bench.py's cpu_baseline) ORC_QB queries are scored at a time with
+ * the query block transposed: the 8 lanes of each AVX2 register are 8 QUERIES, and
+ * _mm256_fmadd_ps is one IEEE fma per lane, so blocking never changes a score.  OpenMP
+ * splits the query blocks over threads. */
+#define ORC_QB 32
 int orc_ip_topk(const float *db, int64_t n, int d, int64_t row_offset, const float *q, int nq, int k, int order,
                 float *out_s, int64_t *out_i) {
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int qi = 0; qi < nq; ++qi) {
-        float *ls = out_s + (size_t)qi * k;
-        int64_t *li = out_i + (size_t)qi * k;
-        int cnt = 0;
-        for (int64_t r = 0; r < n; ++r)
-            cnt = topk_insert(ls, li, cnt, k, dot_ordered(db + r * d, q + (size_t)qi * d, d, order), row_offset + r);
-        for (; cnt < k; ++cnt) { ls[cnt] = -INFINITY; li[cnt] = -1; }
+    const int nblk = (nq + ORC_QB - 1) / ORC_QB;
+    int *korder = (int *)malloc(sizeof(int) * (size_t)d);
+    if (!korder) return -1;
+    if (order == 1) {
+        const int half = d / 2;
+        for (int s = 0; s < half; ++s) { korder[2 * s] = s; korder[2 * s + 1] = half + s; }
+    } else {
+        for (int c = 0; c < d; ++c) korder[c] = c;
     }
-    return 0;
+    int fail = 0;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < nblk; ++b) {
+        const int q0 = b * ORC_QB, qb = (nq - q0 < ORC_QB) ? nq - q0 : ORC_QB;
+        float *qT = (float *)aligned_alloc(64, sizeof(float) * (size_t)d * ORC_QB); /* [chain step][query] */
+        int cnt[ORC_QB];
+        float thr[ORC_QB];
+        if (!qT) { fail = 1; continue; }
+        for (int c = 0; c < d; ++c)
+            for (int j = 0; j < ORC_QB; ++j)
+                qT[(size_t)c * ORC_QB + j] = (j < qb) ? q[(size_t)(q0 + j) * d + korder[c]] : 0.0f;
+        for (int j = 0; j < ORC_QB; ++j) { cnt[j] = 0; thr[j] = -INFINITY; }
+        for (int64_t r = 0; r < n; ++r) {
+            const float *row = db + r * d;
+            float acc[ORC_QB] __attribute__((aligned(32)));
+            __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+            for (int c = 0; c < d; ++c) {
+                const __m256 a = _mm256_set1_ps(row[korder[c]]);
+                const float *qq = qT + (size_t)c * ORC_QB;
+                a0 = _mm256_fmadd_ps(a, _mm256_load_ps(qq), a0);
+                a1 = _mm256_fmadd_ps(a, _mm256_load_ps(qq + 8), a1);
+                a2 = _mm256_fmadd_ps(a, _mm256_load_ps(qq + 16), a2);
+                a3 = _mm256_fmadd_ps(a, _mm256_load_ps(qq + 24), a3);
+            }
+            _mm256_store_ps(acc, a0); _mm256_store_ps(acc + 8, a1);
+            _mm256_store_ps(acc + 16, a2); _mm256_store_ps(acc + 24, a3);
+            for (int j = 0; j < qb; ++j) {
+                /* rows arrive in ascending order, so a tie with the k-th best never wins */
+                if (cnt[j] == k && !(acc[j] > thr[j])) continue;
+                float *ls = out_s + (size_t)(q0 + j) * k;
+                int64_t *li = out_i + (size_t)(q0 + j) * k;
+                cnt[j] = topk_insert(ls, li, cnt[j], k, acc[j], row_offset + r);
+                if (cnt[j] == k) thr[j] = ls[k - 1];
+            }
+        }
+        for (int j = 0; j < qb; ++j) {
+            float *ls = out_s + (size_t)(q0 + j) * k;
+            int64_t *li = out_i + (size_t)(q0 + j) * k;
+            for (int c = cnt[j]; c < k; ++c) { ls[c] = -INFINITY; li[c] = -1; }
+        }
+        free(qT);
+    }
+    free(korder);
+    return fail ? -1 : 0;
 }
 
 /* faiss.ResultHeap(nq, k, keep_max=True).add_result(D, I) ... .finalize(), dbsearch.py:224,

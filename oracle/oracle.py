@@ -42,6 +42,11 @@ def _f32(a):
     return a, a.ctypes.data_as(_f32p)
 
 
+def num_threads() -> int:
+    """OpenMP threads the oracle's parallel loops use."""
+    return int(lib().orc_num_threads())
+
+
 def layer_floats() -> int:
     return int(lib().orc_layer_floats())
 

@@ -70,6 +70,10 @@ def load() -> ctypes.CDLL:
         raise MerizoHipError(
             f"{LIB_PATH} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
             "This package has no CPU fallback.")
+    # torch bundles its own HIP runtime: import it FIRST so that this library's libamdhip64
+    # dependency resolves to the copy torch already loaded (one runtime per process; loading
+    # the system copy first makes torch.cuda report no devices).
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as exc:  # pragma: no cover - depends on the host

@@ -90,278 +90,389 @@ struct ScanParams {
     const float *qn;        // [nq_pad,128] prepared queries
     int nq;                 // real queries
     int nq_pad;
-    int k;                  // entries per list this pass (<= 64)
-    int mode;
+    int k;                  // ranks wanted this pass (<= 2*KL <= 64)
     const float *inv_norm;  // [n] or NULL
     const float *lengths;   // [n] or NULL
     const float *qlen;      // [nq] or NULL
     float mincov;
-    const float *ub_s;      // [nq_pad] exclusive upper bound of this pass, or NULL (first pass)
+    const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;
-    float *part_s;          // [n_chunks, nq_pad, k]
+    float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
-    int rows_per_chunk;     // multiple of the tile height
-    int n_chunks;
+    int rows_per_stream;    // multiple of 32
+    int n_streams;          // row streams (one wave each per query tile)
+    int n_qtiles;           // 32-query tiles
+    int qwb;                // query tiles per workgroup: 4, 2 or 1 (the other 4/qwb waves take other streams)
     int n_qgroups;
+    int n_sgroups;          // stream groups = workgroups per query group
+    int P;                  // partial lists per query written by this launch
 };
 
-template <int QW>
-__global__ __launch_bounds__(256, 2) void ms_scan_kernel(const ScanParams p) {
-    constexpr int RW = 4 / QW;          // row sub-tiles per staged tile
-    constexpr int TROWS = 32 * RW;      // rows per staged tile
-    constexpr int LD_IT = 4 * RW;       // float4 loads per thread per tile
+// value of `x` in the partner lane (lane ^ 32): one v_permlane32_swap + one select, no LDS
+__device__ __forceinline__ uint32_t ms_xor32_u(uint32_t x, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return h ? r[0] : r[1];
+}
+__device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_float(ms_xor32_u(__float_as_uint(x), h)); }
+
+// One wave = one (query tile, row stream) pair; waves never synchronise with each other
+// inside the scan.  Per 32-row tile:
+//   LDS-DMA (global_load_lds_dwordx4, 16 x 1 KiB) brings the tile into this wave's private
+//   16 KiB LDS slot -- lane-linear destination, XOR-swizzled SOURCE address -- while the
+//   previous tile is being multiplied;  16 ds_read_b128 pull the whole tile into 64 VGPRs in
+//   MFMA A-fragment order;  64 x v_mfma_f32_32x32x2_f32 against the resident query tile;
+//   then the filter: one compare per score against the query's k-th best so far.
+// The running top-k of query q lives in the REGISTERS of its two lanes (q, q+32): lane q holds
+// ranks 0..KL-1, lane q+32 ranks KL..2KL-1, sorted.  An insertion step handles one database
+// row for all 32 queries at once (SIMD over queries): the candidate goes to lane q, lane q's
+// displaced last entry (one compare tells which) goes to lane q+32, both lanes run one
+// compare-exchange chain.  No LDS, no atomics, no cross-wave traffic.
+template <int KL>
+__global__ __launch_bounds__(256, (KL > 8 ? 1 : 2)) void ms_scan_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *tile = reinterpret_cast<f32x4 *>(smem);                       // TROWS x 32 float4, swizzled
-    uint2 *lists = reinterpret_cast<uint2 *>(smem + (size_t)TROWS * 512); // [4 waves][32 queries][k]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int qw = wave / RW, rw = wave % RW;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
+    // below becomes 64-bit per-lane arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int k = p.k;
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem + wave * 16384);   // this wave's 32 x 32 float4 slot
 
-    // block id -> (row chunk, query group).  Blocks that share a row chunk get ids that differ
-    // by multiples of 8: the dispatcher deals ids round-robin over the 8 XCDs, so they land on
-    // one XCD close in time and the chunk's rows are served by that XCD's L2 (speed only).
+    // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
     const int per_super = 8 * p.n_qgroups;
     const int super = bid / per_super, within = bid % per_super;
-    int chunk = super * 8 + (within & 7);
-    int qg = within >> 3;
-    if (chunk >= p.n_chunks) return;   // last super-group may be ragged (uniform per block)
+    const int sgroup = super * 8 + (within & 7);
+    const int qg = within >> 3;
+    if (sgroup >= p.n_sgroups) return;
+    const int spb = 4 / p.qwb;
+    const int qw = wave % p.qwb, sw = wave / p.qwb;
+    const int stream = sgroup * spb + sw;
+    const int qtile = qg * p.qwb + qw;
+    const bool active = stream < p.n_streams && qtile < p.n_qtiles;
 
-    const int64_t row_begin = (int64_t)chunk * p.rows_per_chunk;
-    const int64_t row_end = (row_begin + p.rows_per_chunk < p.n) ? row_begin + p.rows_per_chunk : p.n;
-    const int ntiles = (int)((row_end - row_begin + TROWS - 1) / TROWS);
-
-    // this lane's query
-    const int qidx = (qg * QW + qw) * 32 + r;
-    const bool q_valid = qidx < p.nq;
-
-    // B operand: query tile, resident for the whole kernel.  lane (q = r, h) holds
-    // Q[q][64 h + s], s = 0..63.
-    float qreg[64];
-    {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+    float ls[KL];
+    uint32_t li[KL];
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const f32x4 v = src[t];
-            qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+    for (int j = 0; j < KL; ++j) { ls[j] = -INFINITY; li[j] = MS_IDX_NONE; }
+
+    if (active) {
+        const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
+        const int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
+        const int ntiles = (int)((row_end - row_begin + 31) / 32);
+        const int qidx = qtile * 32 + r;
+        const bool q_valid = qidx < p.nq;
+
+        // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
+        float qreg[64];
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 v = src[t];
+                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+            }
         }
-    }
-    const float my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
-    float ubs = INFINITY;
-    uint32_t ubi = 0;
-    const bool has_ub = p.ub_s != nullptr;
-    if (has_ub) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
+        const float my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+        const bool has_ub = p.ub_s != nullptr;
+        float ubs = INFINITY;
+        uint32_t ubi = 0;
+        if (has_ub) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
+#ifdef MS_DEBUG_NO_INSERT
+        float tau = INFINITY;
+#else
+        float tau = -INFINITY;
+#endif
 
-    // empty lists
-    uint2 *my_lists = lists + (size_t)wave * 32 * k;
-    for (int e = lane; e < 32 * k; e += 64) my_lists[e] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
-    float tau = -INFINITY;
-
-    // register prefetch of the first tile
-    f32x4 pre[LD_IT];
-    auto issue_loads = [&](int t) {
-        const int64_t base_row = row_begin + (int64_t)t * TROWS;
+        // LDS-DMA of one tile.  Instruction `it` fills slots 64 it .. 64 it + 63, i.e. rows
+        // 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
+        // Per-lane byte offset inside the tile for instruction it:
+        //     (2 it + h) * 512 + 16 * ((r ^ h) ^ (2 it & 15))
+        // = it * 1024 [scalar] + off8[it & 7] [8 VGPRs computed once].
+        uint32_t off8[8];
 #pragma unroll
-        for (int it = 0; it < LD_IT; ++it) {
-            const int f = it * 256 + tid;
-            const int64_t grow = base_row + (f >> 5);
-            if (grow < row_end)
-                pre[it] = *(reinterpret_cast<const f32x4 *>(p.db + grow * MS_DIM) + (f & 31));
-            else
-                pre[it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-        }
-    };
-    issue_loads(0);
-
-    for (int t = 0; t < ntiles; ++t) {
-        // registers -> LDS (swizzled: float4 slot c4 of row rr lives at c4 ^ (rr & 15))
+        for (int c = 0; c < 8; ++c) off8[c] = (uint32_t)(h * 512 + 16 * ((r ^ h) ^ (2 * c)));
+        auto issue_dma = [&](int t) {
+            const int64_t row0 = row_begin + (int64_t)t * 32;
+            const char *tile_src = reinterpret_cast<const char *>(p.db) + row0 * 512;
+            if (row0 + 32 <= p.n) {
 #pragma unroll
-        for (int it = 0; it < LD_IT; ++it) {
-            const int f = it * 256 + tid;
-            const int rr = f >> 5, c4 = f & 31;
-            tile[rr * 32 + (c4 ^ (rr & 15))] = pre[it];
-        }
-        __syncthreads();
-        if (t + 1 < ntiles) issue_loads(t + 1);
-
-        // ---- S[32 rows x 32 queries] = D_tile . Q_tile^T on the matrix cores ----
-        f32x16 acc;
+                for (int it = 0; it < 16; ++it) {
+                    const char *src = tile_src + it * 1024 + off8[it & 7];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tile + it * 64), 16, 0, 0);
+                }
+            } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-        const f32x4 *arow = tile + (rw * 32 + r) * 32;
-#pragma unroll
-        for (int tt = 0; tt < 16; ++tt) {
-            const f32x4 a = arow[(16 * h + tt) ^ (r & 15)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-        }
-
-        // ---- epilogue: scale / mask, filter against the k-th best, rare insert ----
-        const int64_t sub_row0 = row_begin + (int64_t)t * TROWS + rw * 32;  // first row of this wave's sub-tile
-        const bool sub_full = sub_row0 + 32 <= row_end;
-        float sc[16];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float iv[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            const int64_t rbase = sub_row0 + 8 * g + 4 * h;
-            if (p.inv_norm != nullptr) {
-                if (sub_full) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p.inv_norm + rbase);
-                    iv[0] = v.x; iv[1] = v.y; iv[2] = v.z; iv[3] = v.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) iv[j] = (rbase + j < row_end) ? p.inv_norm[rbase + j] : 0.0f;
+                for (int it = 0; it < 16; ++it) {
+                    int64_t row = row0 + 2 * it + h;
+                    if (row >= p.n) row = p.n - 1;
+                    const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(tile + it * 64), 16, 0, 0);
                 }
             }
+        };
+        if (ntiles > 0) issue_dma(0);
+
+        for (int t = 0; t < ntiles; ++t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t has landed in this wave's slot
+            f32x4 areg[16];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc[4 * g + j] = (p.inv_norm != nullptr) ? acc[4 * g + j] * iv[j] : acc[4 * g + j];
-            if (p.lengths != nullptr) {
-                float ln[4];
-                if (sub_full) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(p.lengths + rbase);
-                    ln[0] = v.x; ln[1] = v.y; ln[2] = v.z; ln[3] = v.w;
-                } else {
+            for (int tt = 0; tt < 16; ++tt) areg[tt] = tile[r * 32 + ((16 * h + tt) ^ (r & 15))];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot fully read before it is refilled
+            if (t + 1 < ntiles) issue_dma(t + 1);
+
+            // ---- S[32 rows x 32 queries] = D_tile . Q_tile^T ----
+            f32x16 acc;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) ln[j] = (rbase + j < row_end) ? p.lengths[rbase + j] : 0.0f;
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].w, qreg[4 * tt + 3], acc, 0, 0, 0);
+            }
+
+            // ---- epilogue: scale / mask, filter against the k-th best, rare insertion steps ----
+            const int64_t sub_row0 = row_begin + (int64_t)t * 32;
+            const bool sub_full = sub_row0 + 32 <= row_end;
+            float sc[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sc[4 * g + j] = acc[4 * g + j];
+                if (p.inv_norm != nullptr) {
+                    float iv[4];
+                    if (sub_full) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.inv_norm + rbase);
+                        iv[0] = v.x; iv[1] = v.y; iv[2] = v.z; iv[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) iv[j] = (rbase + j < row_end) ? p.inv_norm[rbase + j] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sc[4 * g + j] = sc[4 * g + j] * iv[j];
                 }
+                if (p.lengths != nullptr) {
+                    float ln[4];
+                    if (sub_full) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.lengths + rbase);
+                        ln[0] = v.x; ln[1] = v.y; ln[2] = v.z; ln[3] = v.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) ln[j] = (rbase + j < row_end) ? p.lengths[rbase + j] : 0.0f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float m = (my_qlen >= ln[j] * p.mincov) ? 1.0f : 0.0f;   // dbsearch.py:76
+                        sc[4 * g + j] = sc[4 * g + j] * m;                              // dbsearch.py:78
+                    }
+                }
+            }
+
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint64_t m[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float m = (my_qlen >= ln[j] * p.mincov) ? 1.0f : 0.0f;   // dbsearch.py:76
-                    sc[4 * g + j] = sc[4 * g + j] * m;                              // dbsearch.py:78
+                    const float s = sc[4 * g + j];
+                    const uint32_t lrow = (uint32_t)(sub_row0 + 8 * g + 4 * h + j);
+                    bool pass = q_valid && (s > tau);
+                    if (!sub_full) pass = pass && (sub_row0 + 8 * g + 4 * h + j < row_end);
+                    if (has_ub) pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
+                    m[j] = __ballot(pass);
                 }
-            }
-        }
-
+                if ((m[0] | m[1] | m[2] | m[3]) == 0) continue;
+                // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint64_t m[4];
+                for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float s = sc[4 * g + j];
-                const uint32_t lrow = (uint32_t)(sub_row0 + 8 * g + 4 * h + j);
-                bool pass = q_valid && (s > tau);
-                if (!sub_full) pass = pass && (sub_row0 + 8 * g + 4 * h + j < row_end);
-                if (has_ub) pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
-                m[j] = __ballot(pass);
-            }
-            if ((m[0] | m[1] | m[2] | m[3]) == 0) continue;
-            // ascending row order: rows 8g+4hh+j
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t mm = hh ? (uint32_t)(m[j] >> 32) : (uint32_t)m[j];
-                    while (mm) {
-                        const int b = __builtin_ctz(mm);
-                        mm &= mm - 1;
-                        const float cs = ms_readlane_f(sc[4 * g + j], b + 32 * hh);
+                    for (int j = 0; j < 4; ++j) {
+                        const uint32_t mm = hh ? (uint32_t)(m[j] >> 32) : (uint32_t)m[j];
+                        if (mm == 0) continue;
                         const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
-                        const float nt = ms_wave_insert(my_lists + b * k, k, cs, crow, lane);
-                        if (r == b) tau = nt;
+                        // candidate of this lane pair (or -inf); re-checked against the current tau
+                        const float v = sc[4 * g + j];
+                        const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > tau);
+                        const float c = mine ? v : -INFINITY;
+                        const float pc = ms_xor32_f(c, h);
+                        const float cand = (h == hh) ? c : pc;
+                        // lane q+32 receives lane q's last entry if the candidate displaces it
+                        const float pl_s = ms_xor32_f(ls[KL - 1], h);
+                        const uint32_t pl_i = ms_xor32_u(li[KL - 1], h);
+                        const bool spill = (h == 1) && (cand > pl_s);
+                        float in_s = spill ? pl_s : cand;
+                        uint32_t in_i = spill ? pl_i : crow;
+                        if (h == 0) { in_s = cand; in_i = crow; }
+                        bool taken = false;
+#pragma unroll
+                        for (int e = 0; e < KL; ++e) {
+                            // new rows lose ties (ascending row order); a spilled entry wins them
+                            const bool take = taken || (in_s > ls[e]) || (spill && in_s == ls[e]);
+                            const float ts = ls[e];
+                            const uint32_t ti = li[e];
+                            ls[e] = take ? in_s : ts;
+                            li[e] = take ? in_i : ti;
+                            in_s = take ? ts : in_s;
+                            in_i = take ? ti : in_i;
+                            taken = take;
+                        }
+                        const float worst = ms_xor32_f(ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+                        tau = h ? ls[KL - 1] : worst;
                     }
                 }
             }
         }
-        __syncthreads();   // every wave is done with the tile before it is overwritten
     }
 
-    // ---- combine the RW row-streams of each query tile inside the block ----
-    if (RW > 1) {
-        __syncthreads();
-        // (qw, q) pairs: QW*32 lists to finish; wave w takes pairs w, w+4, ...
-        for (int pair = wave; pair < QW * 32; pair += 4) {
-            const int pqw = pair >> 5, pq = pair & 31;
-            uint2 *dst = lists + ((size_t)(pqw * RW) * 32 + pq) * k;
-            for (int srw = 1; srw < RW; ++srw) {
-                const uint2 *src = lists + ((size_t)(pqw * RW + srw) * 32 + pq) * k;
-                const uint2 e = (lane < k) ? src[lane] : make_uint2(0u, 0u);
-                const uint2 last = dst[k - 1];
-                const bool cand = lane < k && e.y != MS_IDX_NONE &&
-                                  ms_better(__uint_as_float(e.x), e.y, __uint_as_float(last.x), last.y);
-                const int c = __popcll(__ballot(cand));   // sorted source: survivors form a prefix
-                for (int i = 0; i < c; ++i)
-                    ms_wave_insert(dst, k, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
+    // ---- write the lists.  qwb == 4: one partial list per (stream, query).  qwb < 4: the
+    //      4/qwb streams of a query tile inside this workgroup are merged through LDS first. ----
+    constexpr int K2 = 2 * KL;
+    if (p.qwb == 4) {
+        if (!active) return;
+        const int qidx = qtile * 32 + r;
+#pragma unroll
+        for (int j = 0; j < KL; ++j) {
+            const int rank = h * KL + j;
+            if (rank < p.k) {
+                const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+                p.part_s[o] = ls[j];
+                p.part_i[o] = li[j];
             }
         }
-        __syncthreads();
-    } else {
-        __syncthreads();
+        return;
     }
-
-    // ---- write this block's lists: part[chunk][query][k] ----
-    for (int e = tid; e < QW * 32 * k; e += 256) {
-        const int lq = e / k, j = e % k;             // lq = qw*32 + q
+    __syncthreads();                                   // every wave is done with its tile slot
+    uint2 *lists = reinterpret_cast<uint2 *>(smem);    // [qw][sw][32 queries][K2]
+    {
+        uint2 *mine = lists + ((size_t)(qw * spb + sw) * 32 + r) * K2 + h * KL;
+#pragma unroll
+        for (int j = 0; j < KL; ++j) mine[j] = make_uint2(__float_as_uint(ls[j]), li[j]);
+    }
+    __syncthreads();
+    for (int pair = wave; pair < p.qwb * 32; pair += 4) {
+        const int pqw = pair >> 5, pq = pair & 31;
+        uint2 *dst = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;
+        for (int s2 = 1; s2 < spb; ++s2) {
+            const uint2 *src = lists + ((size_t)(pqw * spb + s2) * 32 + pq) * K2;
+            const uint2 e = (lane < K2) ? src[lane] : make_uint2(0u, MS_IDX_NONE);
+            const uint2 last = dst[K2 - 1];
+            const bool cand = lane < K2 && e.y != MS_IDX_NONE &&
+                              ms_better(__uint_as_float(e.x), e.y, __uint_as_float(last.x), last.y);
+            const int c = __popcll(__ballot(cand));   // sorted source: survivors form a prefix
+            for (int i = 0; i < c; ++i)
+                ms_wave_insert(dst, K2, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < p.qwb * 32 * p.k; e += 256) {
+        const int lq = e / p.k, rank = e % p.k;        // lq = qw*32 + q
         const int pqw = lq >> 5, pq = lq & 31;
-        const uint2 v = lists[((size_t)(pqw * RW) * 32 + pq) * k + j];
-        const size_t o = ((size_t)chunk * p.nq_pad + (size_t)qg * QW * 32 + lq) * k + j;
+        const int qt = qg * p.qwb + pqw;
+        if (qt >= p.n_qtiles) continue;
+        const uint2 v = lists[((size_t)(pqw * spb) * 32 + pq) * K2 + rank];
+        const size_t o = ((size_t)(qt * 32 + pq) * p.k + rank) * p.P + sgroup;
         p.part_s[o] = __uint_as_float(v.x);
         p.part_i[o] = v.y;
     }
 }
 
 // ------------------------------------------------------------------ partial merge ------
-// One workgroup per query.  4 waves each reduce a quarter of the per-chunk lists into a sorted
-// list in LDS, wave 0 merges the four, converts rows to int64 (+ row_offset) and records the
-// exclusive upper bound of the next pass.
-__global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part_s, const uint32_t *part_i,
-                                                              int n_chunks, int nq_pad, int k, int64_t row_offset,
-                                                              float *out_s, int64_t *out_i, int out_stride,
-                                                              int out_col0, float *ub_s, uint32_t *ub_i) {
+// One workgroup per query merges its P partial lists (each sorted best-first, rank-major
+// layout [k][P]) into the final top-k:
+//   1. the k-th best of the P list HEADS (k rounds of a block-wide arg-max) is a lower bound
+//      of the answer in the total order (score desc, row asc);
+//   2. only entries at least that good can matter -- a sorted prefix of at most k lists, at
+//      most k*k entries in all -- they are appended to an LDS pool;
+//   3. one wave inserts the pool into a sorted k-list (ms_wave_insert) and writes float32 /
+//      int64 results (+ the exclusive bound of the next pass when k > 64).
+constexpr int MERGE_MAX_P = 1024;
+__global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part_s, const uint32_t *part_i, int P,
+                                                              int k, int64_t row_offset, float *out_s, int64_t *out_i,
+                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *lists = reinterpret_cast<uint2 *>(smem);   // [4][k]
+    uint2 *pool = reinterpret_cast<uint2 *>(smem);              // [k*k]
+    uint2 *list = pool + (size_t)k * k;                         // [k]
+    __shared__ float red_s[4];
+    __shared__ uint32_t red_i[4];
+    __shared__ int red_slot[4];
+    __shared__ int pool_count;
     const int q = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint2 *mine = lists + wave * k;
-    if (lane < k) mine[lane] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
-    constexpr int UNROLL = 8;
-    for (int c0 = wave * UNROLL; c0 < n_chunks; c0 += 4 * UNROLL) {
-        float es[UNROLL];
-        uint32_t ei[UNROLL];
+    const float *ps = part_s + (size_t)q * k * P;
+    const uint32_t *pi = part_i + (size_t)q * k * P;
+    constexpr int PER = MERGE_MAX_P / 256;
+    float hs[PER];
+    uint32_t hi[PER];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const int c = c0 + u;
-            es[u] = -INFINITY;
-            ei[u] = MS_IDX_NONE;
-            if (c < n_chunks && lane < k) {
-                const size_t o = ((size_t)c * nq_pad + q) * k + lane;
-                es[u] = part_s[o];
-                ei[u] = part_i[o];
-            }
+    for (int u = 0; u < PER; ++u) {
+        const int pp = tid + u * 256;
+        hs[u] = -INFINITY; hi[u] = MS_IDX_NONE;
+        if (pp < P) { hs[u] = ps[pp]; hi[u] = pi[pp]; }
+    }
+    if (tid == 0) pool_count = 0;
+    // 1. k-th best head
+    float th_s = -INFINITY;
+    uint32_t th_i = MS_IDX_NONE;
+    for (int round = 0; round < k; ++round) {
+        float bs = -INFINITY; uint32_t bi = MS_IDX_NONE; int bslot = -1;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (hi[u] != MS_IDX_NONE && (bslot < 0 || ms_better(hs[u], hi[u], bs, bi))) { bs = hs[u]; bi = hi[u]; bslot = tid + u * 256; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off);
+            const uint32_t oi = __shfl_xor(bi, off);
+            const int oslot = __shfl_xor(bslot, off);
+            if (oslot >= 0 && (bslot < 0 || ms_better(os, oi, bs, bi))) { bs = os; bi = oi; bslot = oslot; }
         }
+        if (lane == 0) { red_s[wave] = bs; red_i[wave] = bi; red_slot[wave] = bslot; }
+        __syncthreads();
+        bs = red_s[0]; bi = red_i[0]; bslot = red_slot[0];
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const uint2 last = mine[k - 1];
-            const bool cand = ei[u] != MS_IDX_NONE && ms_better(es[u], ei[u], __uint_as_float(last.x), last.y);
-            const int c = __popcll(__ballot(cand));
-            for (int i = 0; i < c; ++i) ms_wave_insert(mine, k, ms_readlane_f(es[u], i), ms_readlane_u(ei[u], i), lane);
+        for (int w = 1; w < 4; ++w)
+            if (red_slot[w] >= 0 && (bslot < 0 || ms_better(red_s[w], red_i[w], bs, bi))) { bs = red_s[w]; bi = red_i[w]; bslot = red_slot[w]; }
+        __syncthreads();
+        if (bslot < 0) { th_s = -INFINITY; th_i = MS_IDX_NONE; break; }   // fewer than k non-empty lists: keep everything
+        th_s = bs; th_i = bi;
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+            if (bslot == tid + u * 256) hi[u] = MS_IDX_NONE;              // remove the winner
+    }
+    // 2. pool of entries not worse than the threshold
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pp = tid + u * 256;
+        if (pp >= P) continue;
+        for (int j = 0; j < k; ++j) {
+            const float s = ps[(size_t)j * P + pp];
+            const uint32_t i = pi[(size_t)j * P + pp];
+            if (i == MS_IDX_NONE) break;
+            if (th_i != MS_IDX_NONE && ms_better(th_s, th_i, s, i)) break;     // strictly worse than the threshold
+            const int slot = atomicAdd(&pool_count, 1);
+            if (slot < k * k) pool[slot] = make_uint2(__float_as_uint(s), i);
         }
     }
+    if (tid < k) list[tid] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
     __syncthreads();
+    // 3. final selection by one wave
     if (wave == 0) {
-        for (int w = 1; w < 4; ++w) {
-            const uint2 e = (lane < k) ? lists[w * k + lane] : make_uint2(0u, MS_IDX_NONE);
-            const uint2 last = mine[k - 1];
-            const bool cand = lane < k && e.y != MS_IDX_NONE &&
-                              ms_better(__uint_as_float(e.x), e.y, __uint_as_float(last.x), last.y);
-            const int c = __popcll(__ballot(cand));
-            for (int i = 0; i < c; ++i)
-                ms_wave_insert(mine, k, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
+        const int count = pool_count < k * k ? pool_count : k * k;
+        for (int c0 = 0; c0 < count; c0 += 64) {
+            const int idx = c0 + lane;
+            const uint2 e = idx < count ? pool[idx] : make_uint2(0u, MS_IDX_NONE);
+            const int nn = (count - c0) < 64 ? (count - c0) : 64;
+            for (int i = 0; i < nn; ++i)
+                ms_wave_insert(list, k, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
         }
         if (lane < k) {
-            const uint2 e = mine[lane];
+            const uint2 e = list[lane];
             const size_t o = (size_t)q * out_stride + out_col0 + lane;
-            if (out_s != nullptr) {
-                out_s[o] = __uint_as_float(e.x);
-                out_i[o] = (e.y == MS_IDX_NONE) ? (int64_t)-1 : row_offset + (int64_t)e.y;
-            }
-            if (lane == k - 1 && ub_s != nullptr) {
-                ub_s[q] = __uint_as_float(e.x);
-                ub_i[q] = e.y;
-            }
+            out_s[o] = __uint_as_float(e.x);
+            out_i[o] = (e.y == MS_IDX_NONE) ? (int64_t)-1 : row_offset + (int64_t)e.y;
+            if (lane == k - 1 && ub_s != nullptr) { ub_s[q] = __uint_as_float(e.x); ub_i[q] = e.y; }
         }
     }
 }
@@ -397,12 +508,10 @@ __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores, 
 namespace {
 
 struct ScanPlan {
-    int qw;            // query tiles per workgroup (1, 2 or 4)
-    int n_qgroups;
-    int nq_pad;
-    int k_pass;        // list length per pass
-    int rows_per_chunk;
-    int n_chunks;
+    int n_qtiles, qwb, n_qgroups, nq_pad;
+    int k_pass;            // ranks per pass (<= 64)
+    int kl;                // list entries per lane: smallest of {1,3,5,8,16,32} with 2*kl >= k_pass
+    int rows_per_stream, n_streams, n_sgroups, P;
     int grid;
     size_t lds_bytes;
     // workspace carve (byte offsets)
@@ -419,30 +528,41 @@ int cu_count_cached() {
     return cus;
 }
 
+int pick_kl(int k_pass) {
+    const int opts[6] = {1, 3, 5, 8, 16, 32};
+    for (int i = 0; i < 6; ++i)
+        if (2 * opts[i] >= k_pass) return opts[i];
+    return 32;
+}
+
 ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     ScanPlan pl;
-    const int ntiles_q = (nq + 31) / 32;
-    pl.qw = ntiles_q >= 3 ? 4 : (ntiles_q == 2 ? 2 : 1);
-    pl.n_qgroups = (ntiles_q + pl.qw - 1) / pl.qw;
-    pl.nq_pad = pl.n_qgroups * pl.qw * 32;
+    pl.n_qtiles = (nq + 31) / 32;
+    pl.qwb = pl.n_qtiles >= 3 ? 4 : (pl.n_qtiles == 2 ? 2 : 1);
+    pl.n_qgroups = (pl.n_qtiles + pl.qwb - 1) / pl.qwb;
+    pl.nq_pad = pl.n_qgroups * pl.qwb * 32;
     pl.k_pass = k < 64 ? k : 64;
-    const int trows = 32 * (4 / pl.qw);
-    const int64_t tiles = (n + trows - 1) / trows;
-    int64_t want = (2LL * cus + pl.n_qgroups - 1) / pl.n_qgroups;   // ~2 workgroups per CU in total
+    pl.kl = pick_kl(pl.k_pass);
+    const int waves_per_simd = pl.kl > 8 ? 1 : 2;
+    const int64_t tiles = (n + 31) / 32;
+    // one wave per (query tile, stream): aim at waves_per_simd waves on each of the 4*cus SIMDs
+    int64_t want = ((int64_t)waves_per_simd * 4 * cus) / ((int64_t)pl.n_qgroups * pl.qwb);
     if (want < 1) want = 1;
     if (want > tiles) want = tiles > 0 ? tiles : 1;
-    const int64_t tiles_per_chunk = (tiles + want - 1) / want;
-    pl.rows_per_chunk = (int)((tiles_per_chunk > 0 ? tiles_per_chunk : 1) * trows);
-    pl.n_chunks = (int)((n + pl.rows_per_chunk - 1) / pl.rows_per_chunk);
-    if (pl.n_chunks < 1) pl.n_chunks = 1;
-    const int supers = (pl.n_chunks + 7) / 8;
-    pl.grid = supers * 8 * pl.n_qgroups;
-    pl.lds_bytes = (size_t)trows * 512 + (size_t)4 * 32 * pl.k_pass * sizeof(uint2);
+    const int64_t tiles_per_stream = (tiles + want - 1) / want;
+    pl.rows_per_stream = (int)((tiles_per_stream > 0 ? tiles_per_stream : 1) * 32);
+    pl.n_streams = (int)((n + pl.rows_per_stream - 1) / pl.rows_per_stream);
+    if (pl.n_streams < 1) pl.n_streams = 1;
+    const int spb = 4 / pl.qwb;
+    pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
+    pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
+    pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
+    pl.lds_bytes = 4 * 16384;
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);
-    pl.off_part_s = off;  off += ms_align_up((size_t)pl.n_chunks * pl.nq_pad * pl.k_pass * sizeof(float), 256);
-    pl.off_part_i = off;  off += ms_align_up((size_t)pl.n_chunks * pl.nq_pad * pl.k_pass * sizeof(uint32_t), 256);
+    pl.off_part_s = off;  off += ms_align_up((size_t)pl.P * pl.nq_pad * pl.k_pass * sizeof(float), 256);
+    pl.off_part_i = off;  off += ms_align_up((size_t)pl.P * pl.nq_pad * pl.k_pass * sizeof(uint32_t), 256);
     pl.off_ub_s = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
     pl.off_ub_i = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(uint32_t), 256);
     pl.total = off;
@@ -463,28 +583,34 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     return MS_OK;
 }
 
-int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    switch (pl.qw) {
-        case 4: {
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<4>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-            hipLaunchKernelGGL(ms_scan_kernel<4>, dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
-            break;
-        }
-        case 2: {
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<2>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-            hipLaunchKernelGGL(ms_scan_kernel<2>, dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
-            break;
-        }
-        default: {
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<1>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-            hipLaunchKernelGGL(ms_scan_kernel<1>, dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
-            break;
-        }
-    }
+template <int KL>
+int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    hipLaunchKernelGGL(ms_scan_kernel<KL>, dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
     MS_LAUNCH_CHECK("ms_scan_kernel");
+    return MS_OK;
+}
+
+// kp = ranks wanted by this pass (<= pl.k_pass); the list width is chosen per pass
+int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    switch (pick_kl(sp.k)) {
+        case 1: return launch_scan_kl<1>(pl, sp, st);
+        case 3: return launch_scan_kl<3>(pl, sp, st);
+        case 5: return launch_scan_kl<5>(pl, sp, st);
+        case 8: return launch_scan_kl<8>(pl, sp, st);
+        case 16: return launch_scan_kl<16>(pl, sp, st);
+        default: return launch_scan_kl<32>(pl, sp, st);
+    }
+}
+
+int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
+                 int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
+    if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
+    const size_t lds = ((size_t)kp * kp + kp) * sizeof(uint2);
+    hipLaunchKernelGGL(ms_partial_merge_kernel, dim3(nq), dim3(256), lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset,
+                       out_s, out_i, out_stride, col0, ub_s, ub_i);
+    MS_LAUNCH_CHECK("ms_partial_merge_kernel");
     return MS_OK;
 }
 
@@ -505,12 +631,13 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
         MS_LAUNCH_CHECK("ms_row_inv_norms_kernel");
         inv = inv_ws;
     }
-    sp->db = db; sp->n = n; sp->qn = qn; sp->nq = nq; sp->nq_pad = pl.nq_pad; sp->k = pl.k_pass; sp->mode = mode;
+    sp->db = db; sp->n = n; sp->qn = qn; sp->nq = nq; sp->nq_pad = pl.nq_pad; sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
     sp->ub_s = nullptr; sp->ub_i = nullptr;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
-    sp->rows_per_chunk = pl.rows_per_chunk; sp->n_chunks = pl.n_chunks; sp->n_qgroups = pl.n_qgroups;
+    sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
+    sp->qwb = pl.qwb; sp->n_qgroups = pl.n_qgroups; sp->n_sgroups = pl.n_sgroups; sp->P = pl.P;
     return MS_OK;
 }
 
@@ -579,12 +706,10 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
     if (workspace == nullptr || workspace_bytes < pl.total)
         MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_finish: workspace %zu < %zu bytes", workspace_bytes, pl.total);
     char *ws = (char *)workspace;
-    hipLaunchKernelGGL(ms_partial_merge_kernel, dim3(nq), dim3(256), 4 * pl.k_pass * sizeof(uint2), (hipStream_t)stream,
-                       reinterpret_cast<const float *>(ws + pl.off_part_s),
-                       reinterpret_cast<const uint32_t *>(ws + pl.off_part_i), pl.n_chunks, pl.nq_pad, pl.k_pass,
-                       row_offset, out_scores, out_idx, k, 0, (float *)nullptr, (uint32_t *)nullptr);
-    MS_LAUNCH_CHECK("ms_partial_merge_kernel");
-    return MS_OK;
+    ScanParams sp;
+    sp.part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
+    sp.part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
+    return launch_merge(pl, sp, nq, pl.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
@@ -612,10 +737,9 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
         rc = launch_scan(pl, sp, st);
         if (rc) return rc;
         const bool more = col0 + 64 < k;
-        hipLaunchKernelGGL(ms_partial_merge_kernel, dim3(nq), dim3(256), 4 * kp * sizeof(uint2), st, sp.part_s,
-                           sp.part_i, pl.n_chunks, pl.nq_pad, kp, row_offset, out_scores, out_idx, k, col0,
-                           more ? ub_s : (float *)nullptr, more ? ub_i : (uint32_t *)nullptr);
-        MS_LAUNCH_CHECK("ms_partial_merge_kernel");
+        rc = launch_merge(pl, sp, nq, kp, row_offset, out_scores, out_idx, k, col0, more ? ub_s : nullptr,
+                          more ? ub_i : nullptr, st);
+        if (rc) return rc;
         sp.ub_s = ub_s;
         sp.ub_i = ub_i;
     }

@@ -115,27 +115,86 @@ __device__ __forceinline__ uint32_t ms_xor32_u(uint32_t x, int h) {
 }
 __device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_float(ms_xor32_u(__float_as_uint(x), h)); }
 
-// One wave = one (query tile, row stream) pair; waves never synchronise with each other
-// inside the scan.  Per 32-row tile:
-//   LDS-DMA (global_load_lds_dwordx4, 16 x 1 KiB) brings the tile into this wave's private
-//   16 KiB LDS slot -- lane-linear destination, XOR-swizzled SOURCE address -- while the
-//   previous tile is being multiplied;  16 ds_read_b128 pull the whole tile into 64 VGPRs in
-//   MFMA A-fragment order;  64 x v_mfma_f32_32x32x2_f32 against the resident query tile;
-//   then the filter: one compare per score against the query's k-th best so far.
+// One wave = one (query tile, row stream) pair, one wave per SIMD; waves never synchronise
+// with each other inside the scan.  The loop over 32-row tiles is software-pipelined around
+// the dependent chain of 64 v_mfma_f32_32x32x2_f32 of tile t (4096 cycles of matrix pipe):
+//   before the chain   s_waitcnt vmcnt(0): tile t+1 has landed in LDS (issued a tile ago);
+//                      LDS-DMA of tile t+2 (global_load_lds_dwordx4, 16 x 1 KiB) into the slot
+//                      tile t just vacated -- lane-linear destination, XOR-swizzled SOURCE;
+//   in the MFMA gaps   16 ds_read_b128 pull tile t+1 into 64 VGPRs (A-fragment order), and the
+//                      filter of tile t-1 runs: one compare per score against the query's k-th
+//                      best so far;
+//   after the chain    the rare insertion steps for tile t-1.
 // The running top-k of query q lives in the REGISTERS of its two lanes (q, q+32): lane q holds
 // ranks 0..KL-1, lane q+32 ranks KL..2KL-1, sorted.  An insertion step handles one database
 // row for all 32 queries at once (SIMD over queries): the candidate goes to lane q, lane q's
 // displaced last entry (one compare tells which) goes to lane q+32, both lanes run one
-// compare-exchange chain.  No LDS, no atomics, no cross-wave traffic.
+// compare-exchange chain.  No atomics, no cross-wave traffic.
 template <int KL>
-__global__ __launch_bounds__(256, (KL > 8 ? 1 : 2)) void ms_scan_kernel(const ScanParams p) {
+struct ScanState {
+    float ls[KL];
+    uint32_t li[KL];
+    float tau;
+};
+
+// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
+template <int KL>
+__device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
+                                               int64_t sub_row0, int r, int h) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
+        // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t mj = m[4 * g + j];
+                const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+                if (mm == 0) continue;
+                const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
+                // candidate of this lane pair (or -inf); re-checked against the current tau
+                const float v = sc[4 * g + j];
+                const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
+                const float c = mine ? v : -INFINITY;
+                const float pc = ms_xor32_f(c, h);
+                const float cand = (h == hh) ? c : pc;
+                // lane q+32 receives lane q's last entry if the candidate displaces it
+                const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+                const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+                const bool spill = (h == 1) && (cand > pl_s);
+                float in_s = spill ? pl_s : cand;
+                uint32_t in_i = spill ? pl_i : crow;
+                if (h == 0) { in_s = cand; in_i = crow; }
+                bool taken = false;
+#pragma unroll
+                for (int e = 0; e < KL; ++e) {
+                    // new rows lose ties (ascending row order); a spilled entry wins them
+                    const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
+                    const float ts = st.ls[e];
+                    const uint32_t ti = st.li[e];
+                    st.ls[e] = take ? in_s : ts;
+                    st.li[e] = take ? in_i : ti;
+                    in_s = take ? ts : in_s;
+                    in_i = take ? ti : in_i;
+                    taken = take;
+                }
+                const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+                st.tau = h ? st.ls[KL - 1] : worst;
+            }
+        }
+    }
+}
+
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
     // below becomes 64-bit per-lane arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    f32x4 *tile = reinterpret_cast<f32x4 *>(smem + wave * 16384);   // this wave's 32 x 32 float4 slot
+    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
@@ -150,10 +209,14 @@ __global__ __launch_bounds__(256, (KL > 8 ? 1 : 2)) void ms_scan_kernel(const Sc
     const int qtile = qg * p.qwb + qw;
     const bool active = stream < p.n_streams && qtile < p.n_qtiles;
 
-    float ls[KL];
-    uint32_t li[KL];
+    ScanState<KL> st;
 #pragma unroll
-    for (int j = 0; j < KL; ++j) { ls[j] = -INFINITY; li[j] = MS_IDX_NONE; }
+    for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+#ifdef MS_DEBUG_NO_INSERT
+    st.tau = INFINITY;
+#else
+    st.tau = -INFINITY;
+#endif
 
     if (active) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
@@ -172,34 +235,29 @@ __global__ __launch_bounds__(256, (KL > 8 ? 1 : 2)) void ms_scan_kernel(const Sc
                 qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
             }
         }
-        const float my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
-        const bool has_ub = p.ub_s != nullptr;
+        float my_qlen = 0.0f;
+        if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
         float ubs = INFINITY;
         uint32_t ubi = 0;
-        if (has_ub) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
-#ifdef MS_DEBUG_NO_INSERT
-        float tau = INFINITY;
-#else
-        float tau = -INFINITY;
-#endif
+        if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
 
-        // LDS-DMA of one tile.  Instruction `it` fills slots 64 it .. 64 it + 63, i.e. rows
-        // 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
+        // LDS-DMA of one tile into slot (t & 1).  Instruction `it` fills float4 slots 64 it .. 64 it + 63,
+        // i.e. rows 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
         // Per-lane byte offset inside the tile for instruction it:
-        //     (2 it + h) * 512 + 16 * ((r ^ h) ^ (2 it & 15))
-        // = it * 1024 [scalar] + off8[it & 7] [8 VGPRs computed once].
+        //     (2 it + h) * 512 + 16 * ((r ^ h) ^ (2 it & 15))  =  it * 1024 [scalar] + off8[it & 7]
         uint32_t off8[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) off8[c] = (uint32_t)(h * 512 + 16 * ((r ^ h) ^ (2 * c)));
         auto issue_dma = [&](int t) {
             const int64_t row0 = row_begin + (int64_t)t * 32;
+            f32x4 *dst = slot0 + (t & 1) * 1024;
             const char *tile_src = reinterpret_cast<const char *>(p.db) + row0 * 512;
             if (row0 + 32 <= p.n) {
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
                     const char *src = tile_src + it * 1024 + off8[it & 7];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(tile + it * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
                 }
             } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
 #pragma unroll
@@ -208,124 +266,106 @@ __global__ __launch_bounds__(256, (KL > 8 ? 1 : 2)) void ms_scan_kernel(const Sc
                     if (row >= p.n) row = p.n - 1;
                     const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(tile + it * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
                 }
             }
         };
-        if (ntiles > 0) issue_dma(0);
 
-        for (int t = 0; t < ntiles; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // tile t has landed in this wave's slot
-            f32x4 areg[16];
+        // Scores of registers 4g..4g+3 of a finished tile -> sc (cosine mode: * 1/|row|, * length
+        // mask) and pass masks.  Branch-free so that it can sit between the MFMAs of the next
+        // tile; CHECK_ROWS (row < row_end) is only needed for the last tile of a stream, which is
+        // filtered in the drain.
+        auto filter_group = [&](const f32x16 &acc, int64_t sub_row0, int g, bool check_rows, float (&sc)[16],
+                                uint64_t (&m)[16]) {
+            const int64_t rbase = sub_row0 + 8 * g + 4 * h;
 #pragma unroll
-            for (int tt = 0; tt < 16; ++tt) areg[tt] = tile[r * 32 + ((16 * h + tt) ^ (r & 15))];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // slot fully read before it is refilled
-            if (t + 1 < ntiles) issue_dma(t + 1);
+            for (int j = 0; j < 4; ++j) {
+                float s = acc[4 * g + j];
+                if (AUX) {
+                    int64_t ri = rbase + j;                       // clamped: always a valid row of this stream
+                    ri = ri < row_begin ? row_begin : (ri >= row_end ? row_end - 1 : ri);
+                    if (p.inv_norm != nullptr) s = s * p.inv_norm[ri];
+                    if (p.lengths != nullptr) {
+                        const float mk = (my_qlen >= p.lengths[ri] * p.mincov) ? 1.0f : 0.0f;   // dbsearch.py:76
+                        s = s * mk;                                                              // dbsearch.py:78
+                    }
+                }
+                sc[4 * g + j] = s;
+                bool pass = q_valid && (s > st.tau);
+                if (check_rows) pass = pass && (rbase + j < row_end);
+                if (UB) {
+                    const uint32_t lrow = (uint32_t)(rbase + j);
+                    pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
+                }
+                m[4 * g + j] = __ballot(pass);
+            }
+        };
 
-            // ---- S[32 rows x 32 queries] = D_tile . Q_tile^T ----
+        // one pipeline stage: MFMA chain of tile t from `areg`; each fragment register is
+        // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
+        // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
+        f32x4 areg[16];
+        auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; slot t&1 fully read
+            if (t + 2 < ntiles) issue_dma(t + 2);
+            const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
+            const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
+            float sc[16];
+            uint64_t m[16];
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].x, qreg[4 * tt + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].y, qreg[4 * tt + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].z, qreg[4 * tt + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[tt].w, qreg[4 * tt + 3], acc, 0, 0, 0);
+                const f32x4 a = areg[tt];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+                areg[tt] = src[(16 * h + tt) ^ (r & 15)];
+                if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
             }
+            out = acc;
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+        };
 
-            // ---- epilogue: scale / mask, filter against the k-th best, rare insertion steps ----
-            const int64_t sub_row0 = row_begin + (int64_t)t * 32;
-            const bool sub_full = sub_row0 + 32 <= row_end;
+        if (ntiles > 0) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
+            issue_dma(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
+            if (ntiles > 1) issue_dma(1);
+            int t = 0;
+            for (; t + 1 < ntiles; t += 2) {
+                stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
+                stage(t + 1, acc1, acc0);   // acc1 = tile t, acc0 <- tile t+1
+            }
+            if (t < ntiles) {               // odd tail
+                stage(t, acc0, acc1);
+                acc0 = acc1;
+            }
+            // drain: filter + insert the last tile (scores in acc0); it may be partial
             float sc[16];
+            uint64_t m[16];
+            const int64_t last_row0 = row_begin + (int64_t)(ntiles - 1) * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+            for (int g = 0; g < 4; ++g) filter_group(acc0, last_row0, g, true, sc, m);
+            uint64_t any = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) sc[4 * g + j] = acc[4 * g + j];
-                if (p.inv_norm != nullptr) {
-                    float iv[4];
-                    if (sub_full) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.inv_norm + rbase);
-                        iv[0] = v.x; iv[1] = v.y; iv[2] = v.z; iv[3] = v.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) iv[j] = (rbase + j < row_end) ? p.inv_norm[rbase + j] : 0.0f;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) sc[4 * g + j] = sc[4 * g + j] * iv[j];
-                }
-                if (p.lengths != nullptr) {
-                    float ln[4];
-                    if (sub_full) {
-                        const f32x4 v = *reinterpret_cast<const f32x4 *>(p.lengths + rbase);
-                        ln[0] = v.x; ln[1] = v.y; ln[2] = v.z; ln[3] = v.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) ln[j] = (rbase + j < row_end) ? p.lengths[rbase + j] : 0.0f;
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float m = (my_qlen >= ln[j] * p.mincov) ? 1.0f : 0.0f;   // dbsearch.py:76
-                        sc[4 * g + j] = sc[4 * g + j] * m;                              // dbsearch.py:78
-                    }
-                }
-            }
-
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint64_t m[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float s = sc[4 * g + j];
-                    const uint32_t lrow = (uint32_t)(sub_row0 + 8 * g + 4 * h + j);
-                    bool pass = q_valid && (s > tau);
-                    if (!sub_full) pass = pass && (sub_row0 + 8 * g + 4 * h + j < row_end);
-                    if (has_ub) pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
-                    m[j] = __ballot(pass);
-                }
-                if ((m[0] | m[1] | m[2] | m[3]) == 0) continue;
-                // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t mm = hh ? (uint32_t)(m[j] >> 32) : (uint32_t)m[j];
-                        if (mm == 0) continue;
-                        const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
-                        // candidate of this lane pair (or -inf); re-checked against the current tau
-                        const float v = sc[4 * g + j];
-                        const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > tau);
-                        const float c = mine ? v : -INFINITY;
-                        const float pc = ms_xor32_f(c, h);
-                        const float cand = (h == hh) ? c : pc;
-                        // lane q+32 receives lane q's last entry if the candidate displaces it
-                        const float pl_s = ms_xor32_f(ls[KL - 1], h);
-                        const uint32_t pl_i = ms_xor32_u(li[KL - 1], h);
-                        const bool spill = (h == 1) && (cand > pl_s);
-                        float in_s = spill ? pl_s : cand;
-                        uint32_t in_i = spill ? pl_i : crow;
-                        if (h == 0) { in_s = cand; in_i = crow; }
-                        bool taken = false;
-#pragma unroll
-                        for (int e = 0; e < KL; ++e) {
-                            // new rows lose ties (ascending row order); a spilled entry wins them
-                            const bool take = taken || (in_s > ls[e]) || (spill && in_s == ls[e]);
-                            const float ts = ls[e];
-                            const uint32_t ti = li[e];
-                            ls[e] = take ? in_s : ts;
-                            li[e] = take ? in_i : ti;
-                            in_s = take ? ts : in_s;
-                            in_i = take ? ti : in_i;
-                            taken = take;
-                        }
-                        const float worst = ms_xor32_f(ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
-                        tau = h ? ls[KL - 1] : worst;
-                    }
-                }
-            }
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, last_row0, r, h);
         }
     }
+    const int KLc = KL;
+    float (&ls)[KL] = st.ls;
+    uint32_t (&li)[KL] = st.li;
+    (void)KLc;
 
     // ---- write the lists.  qwb == 4: one partial list per (stream, query).  qwb < 4: the
     //      4/qwb streams of a query tile inside this workgroup are merged through LDS first. ----
@@ -510,7 +550,7 @@ namespace {
 struct ScanPlan {
     int n_qtiles, qwb, n_qgroups, nq_pad;
     int k_pass;            // ranks per pass (<= 64)
-    int kl;                // list entries per lane: smallest of {1,3,5,8,16,32} with 2*kl >= k_pass
+    int kl;                // list entries per lane: smallest of {5,16,32} with 2*kl >= k_pass
     int rows_per_stream, n_streams, n_sgroups, P;
     int grid;
     size_t lds_bytes;
@@ -529,8 +569,8 @@ int cu_count_cached() {
 }
 
 int pick_kl(int k_pass) {
-    const int opts[6] = {1, 3, 5, 8, 16, 32};
-    for (int i = 0; i < 6; ++i)
+    const int opts[3] = {5, 16, 32};
+    for (int i = 0; i < 3; ++i)
         if (2 * opts[i] >= k_pass) return opts[i];
     return 32;
 }
@@ -543,7 +583,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.nq_pad = pl.n_qgroups * pl.qwb * 32;
     pl.k_pass = k < 64 ? k : 64;
     pl.kl = pick_kl(pl.k_pass);
-    const int waves_per_simd = pl.kl > 8 ? 1 : 2;
+    const int waves_per_simd = 1;   // the scan is software-pipelined inside each wave
     const int64_t tiles = (n + 31) / 32;
     // one wave per (query tile, stream): aim at waves_per_simd waves on each of the 4*cus SIMDs
     int64_t want = ((int64_t)waves_per_simd * 4 * cus) / ((int64_t)pl.n_qgroups * pl.qwb);
@@ -557,7 +597,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
-    pl.lds_bytes = 4 * 16384;
+    pl.lds_bytes = 4 * 32768;
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);
@@ -583,25 +623,24 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     return MS_OK;
 }
 
-template <int KL>
-int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL>),
+template <int KL, bool AUX, bool UB>
+int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-    hipLaunchKernelGGL(ms_scan_kernel<KL>, dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
     MS_LAUNCH_CHECK("ms_scan_kernel");
     return MS_OK;
 }
 
-// kp = ranks wanted by this pass (<= pl.k_pass); the list width is chosen per pass
+// list width per pass: smallest of {5, 16, 32} entries per lane with 2*KL >= k of the pass
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    switch (pick_kl(sp.k)) {
-        case 1: return launch_scan_kl<1>(pl, sp, st);
-        case 3: return launch_scan_kl<3>(pl, sp, st);
-        case 5: return launch_scan_kl<5>(pl, sp, st);
-        case 8: return launch_scan_kl<8>(pl, sp, st);
-        case 16: return launch_scan_kl<16>(pl, sp, st);
-        default: return launch_scan_kl<32>(pl, sp, st);
-    }
+    const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
+    const bool ub = sp.ub_s != nullptr;
+    const int kl = pick_kl(sp.k);
+    if (ub) return aux ? launch_scan_variant<32, true, true>(pl, sp, st) : launch_scan_variant<32, false, true>(pl, sp, st);
+    if (kl == 5) return aux ? launch_scan_variant<5, true, false>(pl, sp, st) : launch_scan_variant<5, false, false>(pl, sp, st);
+    if (kl == 16) return aux ? launch_scan_variant<16, true, false>(pl, sp, st) : launch_scan_variant<16, false, false>(pl, sp, st);
+    return aux ? launch_scan_variant<32, true, false>(pl, sp, st) : launch_scan_variant<32, false, false>(pl, sp, st);
 }
 
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,

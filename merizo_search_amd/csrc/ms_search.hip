@@ -28,6 +28,7 @@
 #include "ms_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 thread_local char ms_err_buf[512] = "";
 
@@ -97,6 +98,8 @@ struct ScanParams {
     float mincov;
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;
+    const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
+    int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
     int rows_per_stream;    // multiple of 32
@@ -134,7 +137,8 @@ template <int KL>
 struct ScanState {
     float ls[KL];
     uint32_t li[KL];
-    float tau;
+    float tau;     // scores must be > tau to matter: max(k-th best so far, floor)
+    float floor;   // largest float below the sample pass's lower bound (-inf without one)
 };
 
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
@@ -180,7 +184,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
                     taken = take;
                 }
                 const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
-                st.tau = h ? st.ls[KL - 1] : worst;
+                st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
             }
         }
     }
@@ -212,6 +216,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
     ScanState<KL> st;
 #pragma unroll
     for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+    st.floor = -INFINITY;
 #ifdef MS_DEBUG_NO_INSERT
     st.tau = INFINITY;
 #else
@@ -220,10 +225,20 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
 
     if (active) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
-        const int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
+        int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
+        if (p.max_tiles > 0 && row_begin + (int64_t)p.max_tiles * 32 < row_end) row_end = row_begin + (int64_t)p.max_tiles * 32;
         const int ntiles = (int)((row_end - row_begin + 31) / 32);
         const int qidx = qtile * 32 + r;
         const bool q_valid = qidx < p.nq;
+        if (p.lb_s != nullptr) {
+            // s >= lb  <=>  s > nextbelow(lb): at least k sampled rows score >= lb, so anything
+            // below it cannot reach the top k; rows that tie with it still can
+            const float lb = p.lb_s[qidx];
+            st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
+#ifndef MS_DEBUG_NO_INSERT
+            st.tau = st.floor;
+#endif
+        }
 
         // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
         float qreg[64];
@@ -553,9 +568,10 @@ struct ScanPlan {
     int kl;                // list entries per lane: smallest of {5,16,32} with 2*kl >= k_pass
     int rows_per_stream, n_streams, n_sgroups, P;
     int grid;
+    int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
     size_t lds_bytes;
     // workspace carve (byte offsets)
-    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, total;
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, total;
 };
 
 int cu_count_cached() {
@@ -566,6 +582,16 @@ int cu_count_cached() {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
     return cus;
+}
+
+int prepass_tiles_setting() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("MS_PREPASS_TILES");
+        v = e ? atoi(e) : 2;
+        if (v < 0) v = 0;
+    }
+    return v;
 }
 
 int pick_kl(int k_pass) {
@@ -598,6 +624,10 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
     pl.lds_bytes = 4 * 32768;
+    // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
+    // from below and prunes almost every insertion of the full pass; worth it for long streams
+    pl.prepass_tiles = prepass_tiles_setting();
+    if (tiles_per_stream < 16 * (int64_t)pl.prepass_tiles || k > 64) pl.prepass_tiles = 0;
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);
@@ -605,6 +635,10 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.off_part_i = off;  off += ms_align_up((size_t)pl.P * pl.nq_pad * pl.k_pass * sizeof(uint32_t), 256);
     pl.off_ub_s = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
     pl.off_ub_i = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(uint32_t), 256);
+    pl.off_lb_s = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
+    pl.off_lb_i = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(uint32_t), 256);
+    pl.off_scr_s = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(float), 256);
+    pl.off_scr_i = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(int64_t), 256);
     pl.total = off;
     return pl;
 }
@@ -653,6 +687,26 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
     return MS_OK;
 }
 
+// Sample pass: scan the first prepass_tiles tiles of every stream, merge, and leave the k-th
+// best score per query in the workspace (off_ub_s doubles as the buffer) as the lower bound
+// of the full pass.  Outputs of the merge go to scratch inside the partial-list area's tail.
+int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_t st) {
+    if (pl.prepass_tiles <= 0) return MS_OK;
+    ScanParams s0 = *sp;
+    s0.max_tiles = pl.prepass_tiles;
+    s0.lb_s = nullptr;
+    int rc = launch_scan(pl, s0, st);
+    if (rc) return rc;
+    float *lb = reinterpret_cast<float *>(ws + pl.off_lb_s);
+    float *scratch_s = reinterpret_cast<float *>(ws + pl.off_scr_s);
+    int64_t *scratch_i = reinterpret_cast<int64_t *>(ws + pl.off_scr_i);
+    uint32_t *lb_i = reinterpret_cast<uint32_t *>(ws + pl.off_lb_i);
+    rc = launch_merge(pl, s0, nq, s0.k, 0, scratch_s, scratch_i, s0.k, 0, lb, lb_i, st);
+    if (rc) return rc;
+    sp->lb_s = lb;
+    return MS_OK;
+}
+
 // Prepare queries (+ inverse norms if absent) and fill ScanParams for the first pass.
 int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q, int nq, int mode,
                  const float *inv_norm, const float *lengths, const float *qlen, float mincov, char *ws,
@@ -672,7 +726,7 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
     }
     sp->db = db; sp->n = n; sp->qn = qn; sp->nq = nq; sp->nq_pad = pl.nq_pad; sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
-    sp->ub_s = nullptr; sp->ub_i = nullptr;
+    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -734,6 +788,8 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     ScanParams sp;
     rc = prepare_scan(pl, db, n, q, nq, mode, inv_norm, lengths, qlen, mincov, (char *)workspace, (hipStream_t)stream, &sp);
     if (rc) return rc;
+    rc = run_prepass(pl, &sp, nq, (char *)workspace, (hipStream_t)stream);
+    if (rc) return rc;
     return launch_scan(pl, sp, (hipStream_t)stream);
 }
 
@@ -767,6 +823,8 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
     if (rc) return rc;
     float *ub_s = reinterpret_cast<float *>(ws + pl.off_ub_s);
     uint32_t *ub_i = reinterpret_cast<uint32_t *>(ws + pl.off_ub_i);
+    rc = run_prepass(pl, &sp, nq, ws, st);
+    if (rc) return rc;
     // ceil(k / 64) passes; pass p returns ranks [64p, 64p + kp) using the last entry of pass
     // p-1 as an exclusive upper bound in the total order.
     for (int col0 = 0; col0 < k; col0 += 64) {

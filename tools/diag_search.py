@@ -14,7 +14,10 @@ for order in (0, 1):
     print("order", order, "idx equal", np.array_equal(i, ir), "score bits equal", np.array_equal(s.view(np.uint32), sr.view(np.uint32)),
           "max abs diff", float(np.abs(s - sr).max()))
 
-for n, nq, k in ((1_000_000, 256, 10), (1_000_000, 32, 10), (1_000_000, 1, 10), (4_000_000, 256, 10), (1_000_000, 1024, 10)):
+cases = ((1_000_000, 256, 10), (1_000_000, 32, 10), (1_000_000, 1, 10), (4_000_000, 256, 10), (1_000_000, 1024, 10))
+if len(sys.argv) > 1:
+    cases = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+for n, nq, k in cases:
     d = syn.device_database(n, 0, 0, "cuda:0")
     qq = torch.randn(nq, 128, device="cuda"); qq = qq / qq.norm(dim=1, keepdim=True)
     w = ops.TopKWorkspace(d.device); ws = w.get(n, nq, k)

@@ -141,14 +141,66 @@ struct ScanState {
     float floor;   // largest float below the sample pass's lower bound (-inf without one)
 };
 
-// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
+// Candidates that pass the filter are not inserted one by one (an insertion step is SIMD over
+// the 32 queries of the wave and would usually carry a single candidate).  They are appended to
+// small per-query queues in LDS (one ds_add_rtn + one ds_write_b64 per candidate) and the queues
+// are drained together: drain step i inserts the i-th queued candidate of EVERY query at once,
+// so a drain costs max-queue-length steps instead of total-candidates steps.
+constexpr int MS_QCAP = 16;                       // queue entries per query
+constexpr int MS_QBYTES = 32 * 4 + 32 * MS_QCAP * 8;   // counters + entries, per wave
+
+// insert the pair's candidate (cs, ci) -- the same value in both lanes, -inf = none -- into
+// the pair's sorted list; general total order (score desc, row asc)
 template <int KL>
-__device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
-                                               int64_t sub_row0, int r, int h) {
+__device__ __forceinline__ void ms_pair_insert(ScanState<KL> &st, float cs, uint32_t ci, int h) {
+    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);     // lane q+32 sees lane q's last entry
+    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+    const bool spill = (h == 1) && ms_better(cs, ci, pl_s, pl_i);   // candidate displaces it
+    float in_s = spill ? pl_s : cs;
+    uint32_t in_i = spill ? pl_i : ci;
+    if (h == 0) { in_s = cs; in_i = ci; }
+    bool taken = false;
+#pragma unroll
+    for (int e = 0; e < KL; ++e) {
+        const bool take = taken || ms_better(in_s, in_i, st.ls[e], st.li[e]);
+        const float ts = st.ls[e];
+        const uint32_t ti = st.li[e];
+        st.ls[e] = take ? in_s : ts;
+        st.li[e] = take ? in_i : ti;
+        in_s = take ? ts : in_s;
+        in_i = take ? ti : in_i;
+        taken = take;
+    }
+    const float worst = ms_xor32_f(st.ls[KL - 1], h);     // lane q+32's last = the pair's k-th best
+    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+}
+
+// drain all 32 queues of this wave into the register lists
+template <int KL>
+__device__ __forceinline__ void ms_queue_drain(ScanState<KL> &st, uint32_t *qcnt, uint2 *qbuf, int r, int h) {
+    uint32_t cnt = qcnt[r];
+    cnt = cnt < (uint32_t)MS_QCAP ? cnt : (uint32_t)MS_QCAP;
+    for (int step = 0; step < MS_QCAP; ++step) {
+        const bool has = (uint32_t)step < cnt;
+        if (__ballot(has) == 0) break;
+        const uint2 e = qbuf[r * MS_QCAP + step];            // both lanes of the pair read the same entry
+        const float s = __uint_as_float(e.x);
+        const bool live = has && (s > st.tau);               // tau may have risen since it was queued
+        ms_pair_insert<KL>(st, live ? s : -INFINITY, live ? e.y : MS_IDX_NONE, h);
+    }
+    if (h == 0) qcnt[r] = 0;
+}
+
+// queue the candidates of one finished tile (scores sc[16], pass masks m[16]).  Rows are
+// visited in ascending order (row 8g + 4hh + j lives in lanes of half hh, register 4g + j), so
+// whatever a mid-tile drain has already put into the lists comes from smaller rows, and the
+// strict "score > k-th best" test is the exact (score desc, row asc) order.
+template <int KL>
+__device__ __forceinline__ void ms_tile_enqueue(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
+                                                int64_t sub_row0, uint32_t *qcnt, uint2 *qbuf, int r, int h) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
-        // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -156,35 +208,20 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
                 const uint64_t mj = m[4 * g + j];
                 const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
                 if (mm == 0) continue;
-                const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
-                // candidate of this lane pair (or -inf); re-checked against the current tau
+                const uint32_t row = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
                 const float v = sc[4 * g + j];
-                const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
-                const float c = mine ? v : -INFINITY;
-                const float pc = ms_xor32_f(c, h);
-                const float cand = (h == hh) ? c : pc;
-                // lane q+32 receives lane q's last entry if the candidate displaces it
-                const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
-                const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
-                const bool spill = (h == 1) && (cand > pl_s);
-                float in_s = spill ? pl_s : cand;
-                uint32_t in_i = spill ? pl_i : crow;
-                if (h == 0) { in_s = cand; in_i = crow; }
-                bool taken = false;
-#pragma unroll
-                for (int e = 0; e < KL; ++e) {
-                    // new rows lose ties (ascending row order); a spilled entry wins them
-                    const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
-                    const float ts = st.ls[e];
-                    const uint32_t ti = st.li[e];
-                    st.ls[e] = take ? in_s : ts;
-                    st.li[e] = take ? in_i : ti;
-                    in_s = take ? ts : in_s;
-                    in_i = take ? ti : in_i;
-                    taken = take;
+                bool pending = (h == hh) && ((mm >> r) & 1u);
+                for (;;) {
+                    bool queued = true;
+                    if (pending && v > st.tau) {
+                        const uint32_t slot = atomicAdd(&qcnt[r], 1u);     // ds_add_rtn_u32
+                        queued = slot < (uint32_t)MS_QCAP;
+                        if (queued) qbuf[r * MS_QCAP + slot] = make_uint2(__float_as_uint(v), row);
+                    }
+                    pending = pending && !queued;
+                    if (__ballot(pending) == 0) break;
+                    ms_queue_drain<KL>(st, qcnt, qbuf, r, h);               // a queue is full: drain all, retry the rest
                 }
-                const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
-                st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
             }
         }
     }
@@ -199,6 +236,9 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
+    uint32_t *qcnt = reinterpret_cast<uint32_t *>(smem + 4 * 32768 + wave * MS_QBYTES);   // candidate queues
+    uint2 *qbuf = reinterpret_cast<uint2 *>(qcnt + 32);
+    if (lane < 32) qcnt[lane] = 0;
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
@@ -344,7 +384,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
             uint64_t any = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+            if (any != 0) ms_tile_enqueue<KL>(st, sc, m, prev_row0, qcnt, qbuf, r, h);
         };
 
         if (ntiles > 0) {
@@ -374,7 +414,8 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
             uint64_t any = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_insert<KL>(st, sc, m, last_row0, r, h);
+            if (any != 0) ms_tile_enqueue<KL>(st, sc, m, last_row0, qcnt, qbuf, r, h);
+            ms_queue_drain<KL>(st, qcnt, qbuf, r, h);
         }
     }
     const int KLc = KL;
@@ -623,7 +664,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
-    pl.lds_bytes = 4 * 32768;
+    pl.lds_bytes = 4 * 32768 + 4 * MS_QBYTES;
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     pl.prepass_tiles = prepass_tiles_setting();

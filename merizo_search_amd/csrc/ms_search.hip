@@ -139,6 +139,7 @@ struct ScanState {
     uint32_t li[KL];
     float tau;     // scores must be > tau to matter: max(k-th best so far, floor)
     float floor;   // largest float below the sample pass's lower bound (-inf without one)
+    uint32_t qn;   // candidates appended to this query's LDS queue since the last drain (same in both lanes)
 };
 
 // Candidates that pass the filter are not inserted one by one (an insertion step is SIMD over
@@ -147,7 +148,8 @@ struct ScanState {
 // are drained together: drain step i inserts the i-th queued candidate of EVERY query at once,
 // so a drain costs max-queue-length steps instead of total-candidates steps.
 constexpr int MS_QCAP = 16;                       // queue entries per query
-constexpr int MS_QBYTES = 32 * 4 + 32 * MS_QCAP * 8;   // counters + entries, per wave
+constexpr int MS_QSTRIDE = MS_QCAP + 1;            // + one dummy sink entry per query
+constexpr int MS_QBYTES = 32 * MS_QSTRIDE * 8;      // per wave
 
 // insert the pair's candidate (cs, ci) -- the same value in both lanes, -inf = none -- into
 // the pair's sorted list; general total order (score desc, row asc)
@@ -177,27 +179,26 @@ __device__ __forceinline__ void ms_pair_insert(ScanState<KL> &st, float cs, uint
 
 // drain all 32 queues of this wave into the register lists
 template <int KL>
-__device__ __forceinline__ void ms_queue_drain(ScanState<KL> &st, uint32_t *qcnt, uint2 *qbuf, int r, int h) {
-    uint32_t cnt = qcnt[r];
-    cnt = cnt < (uint32_t)MS_QCAP ? cnt : (uint32_t)MS_QCAP;
+__device__ __forceinline__ void ms_queue_drain(ScanState<KL> &st, const uint2 *qbuf, int r, int h) {
+    const uint32_t cnt = st.qn < (uint32_t)MS_QCAP ? st.qn : (uint32_t)MS_QCAP;
     for (int step = 0; step < MS_QCAP; ++step) {
         const bool has = (uint32_t)step < cnt;
         if (__ballot(has) == 0) break;
-        const uint2 e = qbuf[r * MS_QCAP + step];            // both lanes of the pair read the same entry
+        const uint2 e = qbuf[r * MS_QSTRIDE + step];         // both lanes of the pair read the same entry
         const float s = __uint_as_float(e.x);
         const bool live = has && (s > st.tau);               // tau may have risen since it was queued
         ms_pair_insert<KL>(st, live ? s : -INFINITY, live ? e.y : MS_IDX_NONE, h);
     }
-    if (h == 0) qcnt[r] = 0;
+    st.qn = 0;
 }
 
 // queue the candidates of one finished tile (scores sc[16], pass masks m[16]).  Rows are
 // visited in ascending order (row 8g + 4hh + j lives in lanes of half hh, register 4g + j), so
 // whatever a mid-tile drain has already put into the lists comes from smaller rows, and the
 // strict "score > k-th best" test is the exact (score desc, row asc) order.
-template <int KL>
+template <int KL, bool STRICT>
 __device__ __forceinline__ void ms_tile_enqueue(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
-                                                int64_t sub_row0, uint32_t *qcnt, uint2 *qbuf, int r, int h) {
+                                                int64_t sub_row0, uint2 *qbuf, int r, int h) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
@@ -210,18 +211,15 @@ __device__ __forceinline__ void ms_tile_enqueue(ScanState<KL> &st, const float (
                 if (mm == 0) continue;
                 const uint32_t row = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
                 const float v = sc[4 * g + j];
-                bool pending = (h == hh) && ((mm >> r) & 1u);
-                for (;;) {
-                    bool queued = true;
-                    if (pending && v > st.tau) {
-                        const uint32_t slot = atomicAdd(&qcnt[r], 1u);     // ds_add_rtn_u32
-                        queued = slot < (uint32_t)MS_QCAP;
-                        if (queued) qbuf[r * MS_QCAP + slot] = make_uint2(__float_as_uint(v), row);
-                    }
-                    pending = pending && !queued;
-                    if (__ballot(pending) == 0) break;
-                    ms_queue_drain<KL>(st, qcnt, qbuf, r, h);               // a queue is full: drain all, retry the rest
-                }
+                // one candidate per query at most (lanes of half hh); both lanes of the pair track the count.
+                // STRICT: rows arrive in ascending order.  !STRICT (re-queue after an overflow drain that
+                // already holds rows of this tile): ties are kept, the drain's total-order insertion sorts them.
+                const bool mine = (h == hh) && ((mm >> r) & 1u) && (STRICT ? (v > st.tau) : (v >= st.tau));
+                if (__ballot(mine && st.qn >= (uint32_t)MS_QCAP) != 0) ms_queue_drain<KL>(st, qbuf, r, h);
+                const bool again = mine && (STRICT ? (v > st.tau) : (v >= st.tau));   // the drain may have raised tau
+                if (again) qbuf[r * MS_QSTRIDE + st.qn] = make_uint2(__float_as_uint(v), row);
+                const uint32_t inc = again ? 1u : 0u;
+                st.qn += inc + ms_xor32_u(inc, h);
             }
         }
     }
@@ -236,9 +234,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
-    uint32_t *qcnt = reinterpret_cast<uint32_t *>(smem + 4 * 32768 + wave * MS_QBYTES);   // candidate queues
-    uint2 *qbuf = reinterpret_cast<uint2 *>(qcnt + 32);
-    if (lane < 32) qcnt[lane] = 0;
+    uint2 *qbuf = reinterpret_cast<uint2 *>(smem + 4 * 32768 + wave * MS_QBYTES);   // candidate queues
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
@@ -257,6 +253,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
 #pragma unroll
     for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
     st.floor = -INFINITY;
+    st.qn = 0;
 #ifdef MS_DEBUG_NO_INSERT
     st.tau = INFINITY;
 #else
@@ -267,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
         int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
         if (p.max_tiles > 0 && row_begin + (int64_t)p.max_tiles * 32 < row_end) row_end = row_begin + (int64_t)p.max_tiles * 32;
-        const int ntiles = (int)((row_end - row_begin + 31) / 32);
+
         const int qidx = qtile * 32 + r;
         const bool q_valid = qidx < p.nq;
         if (p.lb_s != nullptr) {
@@ -327,11 +324,10 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
         };
 
         // Scores of registers 4g..4g+3 of a finished tile -> sc (cosine mode: * 1/|row|, * length
-        // mask) and pass masks.  Branch-free so that it can sit between the MFMAs of the next
-        // tile; CHECK_ROWS (row < row_end) is only needed for the last tile of a stream, which is
-        // filtered in the drain.
+        // mask) and per-lane pass flags.  Branch-free, so it can sit between the MFMAs of the
+        // next tile.  check_rows (row < row_end) is only needed for a partial last tile.
         auto filter_group = [&](const f32x16 &acc, int64_t sub_row0, int g, bool check_rows, float (&sc)[16],
-                                uint64_t (&m)[16]) {
+                                bool (&pf)[16]) {
             const int64_t rbase = sub_row0 + 8 * g + 4 * h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -352,21 +348,40 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
                     const uint32_t lrow = (uint32_t)(rbase + j);
                     pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
                 }
-                m[4 * g + j] = __ballot(pass);
+                pf[4 * g + j] = pass;
             }
         };
+        // exact, branchy path: ballot the flags and queue in ascending row order
+        auto enqueue_slow = [&](const float (&sc)[16], const bool (&pf)[16], int64_t sub_row0) {
+            uint64_t m[16];
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { m[i] = __ballot(pf[i]); any |= m[i]; }
+            if (any != 0) ms_tile_enqueue<KL, true>(st, sc, m, sub_row0, qbuf, r, h);
+        };
 
-        // one pipeline stage: MFMA chain of tile t from `areg`; each fragment register is
-        // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
-        // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
+        const int nfull = (int)((row_end - row_begin) >> 5);       // full 32-row tiles: the pipelined loop
+        const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
+
+        // One pipeline stage = the MFMA chain of tile t (fragments in `areg`), with everything
+        // else of the neighbouring tiles folded into its gaps, all straight-line code:
+        //   * each fragment register is refilled with tile t+1 right after its 4 MFMAs issued;
+        //   * tile t-1 (scores in `prev`) is filtered, and its candidates are queued with
+        //     unconditional LDS atomics (add 0 for lanes without a candidate) and stores (to a
+        //     dummy slot for those lanes);
+        //   * the LDS-DMA of tile t+2 is issued into the slot tile t vacated.
+        // Only queue overflow and the periodic drain branch, after the chain.
         f32x4 areg[16];
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; slot t&1 fully read
-            if (t + 2 < ntiles) issue_dma(t + 2);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; LDS quiet
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
+            const int tnext = (t + 2 < nfull) ? t + 2 : nfull - 1;           // past the end: harmless re-read
+            const char *dma_src = reinterpret_cast<const char *>(p.db) + (row_begin + (int64_t)tnext * 32) * 512;
+            f32x4 *dma_dst = slot0 + (t & 1) * 1024;
             float sc[16];
-            uint64_t m[16];
+            bool pf[16];
+            bool ovf = false;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -378,16 +393,53 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
                 areg[tt] = src[(16 * h + tt) ^ (r & 15)];
-                if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
+                if (tt >= 1 && tt < 5) filter_group(prev, prev_row0, tt - 1, false, sc, pf);
+                if (tt >= 5 && tt < 9) {
+                    // queue slots from the pair's running count (no LDS atomics), then the stores:
+                    // every lane stores, lanes without a candidate into the dummy entry.  All LDS
+                    // stores of the stage come BEFORE its LDS-DMA issues: hipcc orders a ds_write
+                    // behind every global_load_lds in flight with s_waitcnt vmcnt(0).
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int i = 4 * (tt - 5) + j;
+                        const uint32_t inc = pf[i] ? 1u : 0u;
+                        const uint32_t pinc = ms_xor32_u(inc, h);
+                        const uint32_t slot = st.qn + (h ? pinc : 0u);       // lane q before lane q+32
+                        st.qn += inc + pinc;
+                        const bool fits = slot < (uint32_t)MS_QCAP;
+                        const uint32_t row = (uint32_t)(prev_row0 + (i & 3) + 8 * (i >> 2) + 4 * h);
+                        qbuf[r * MS_QSTRIDE + ((pf[i] && fits) ? slot : (uint32_t)MS_QCAP)] = make_uint2(__float_as_uint(sc[i]), row);
+                        ovf = ovf || (pf[i] && !fits);
+                        pf[i] = pf[i] && !fits;                 // what is left for the overflow path
+                    }
+                }
+                if (tt >= 9) {                                   // the 16 DMA instructions, 3 per step
+#pragma unroll
+                    for (int u = 0; u < 3; ++u) {
+                        const int it = 3 * (tt - 9) + u;
+                        if (it < 16)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + it * 1024 + off8[it & 7]),
+                                                             (__attribute__((address_space(3))) void *)(dma_dst + it * 64), 16, 0, 0);
+                    }
+                }
             }
             out = acc;
-            uint64_t any = 0;
+            if (__ballot(ovf) != 0) {            // some queue overflowed: drain, then queue the leftovers exactly
+                ms_queue_drain<KL>(st, qbuf, r, h);
+                uint64_t m[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_enqueue<KL>(st, sc, m, prev_row0, qcnt, qbuf, r, h);
+                for (int i = 0; i < 16; ++i) m[i] = __ballot(pf[i]);
+                ms_tile_enqueue<KL, false>(st, sc, m, prev_row0, qbuf, r, h);
+            } else if (__ballot(st.qn >= (uint32_t)(MS_QCAP / 2)) != 0) {
+                ms_queue_drain<KL>(st, qbuf, r, h);   // keep the queues shallow and the thresholds fresh
+            }
         };
 
-        if (ntiles > 0) {
+        f32x16 last;   // scores of the tile whose candidates are not queued yet
+#pragma unroll
+        for (int i = 0; i < 16; ++i) last[i] = -INFINITY;
+        int64_t last_row0 = row_begin;
+        if (nfull > 0) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
@@ -395,28 +447,51 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
-            if (ntiles > 1) issue_dma(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_dma(nfull > 1 ? 1 : 0);
             int t = 0;
-            for (; t + 1 < ntiles; t += 2) {
+            for (; t + 1 < nfull; t += 2) {
                 stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
                 stage(t + 1, acc1, acc0);   // acc1 = tile t, acc0 <- tile t+1
             }
-            if (t < ntiles) {               // odd tail
+            if (t < nfull) {                // odd tail
                 stage(t, acc0, acc1);
                 acc0 = acc1;
             }
-            // drain: filter + insert the last tile (scores in acc0); it may be partial
-            float sc[16];
-            uint64_t m[16];
-            const int64_t last_row0 = row_begin + (int64_t)(ntiles - 1) * 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) filter_group(acc0, last_row0, g, true, sc, m);
-            uint64_t any = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_enqueue<KL>(st, sc, m, last_row0, qcnt, qbuf, r, h);
-            ms_queue_drain<KL>(st, qcnt, qbuf, r, h);
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
+            last = acc0;
+            last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
         }
+        {   // candidates of the last full tile (exact path; nothing passes if there was none)
+            float sc[16];
+            bool pf[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) filter_group(last, last_row0, g, true, sc, pf);
+            enqueue_slow(sc, pf, last_row0);
+        }
+        if (rem > 0) {                      // partial last tile of the stream, not pipelined
+            issue_dma(nfull);               // -> slot nfull & 1, rows past the database end clamped
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const f32x4 a = src[(16 * h + tt) ^ (r & 15)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+            }
+            float sc[16];
+            bool pf[16];
+            const int64_t tail_row0 = row_begin + (int64_t)nfull * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) filter_group(acc, tail_row0, g, true, sc, pf);
+            enqueue_slow(sc, pf, tail_row0);
+        }
+        ms_queue_drain<KL>(st, qbuf, r, h);
     }
     const int KLc = KL;
     float (&ls)[KL] = st.ls;

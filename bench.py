@@ -93,9 +93,10 @@ def main():
     shard_merge = ops.topk_merge
 
     def step(events=None):
+        ops.ip_topk_prepare(db, q, k, ws)                               # queries + sample pass (lower bound)
         if events is not None:
             events[0].record()
-        ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel
+        ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE ms_scan_kernel launch
         if events is not None:
             events[1].record()
         ops.ip_topk_finish(n_local, nq, k, ws, out_s, out_i, row_offset=lo)
@@ -154,6 +155,13 @@ def main():
                     "frac": hbm_frac, "traffic": None}
         roof.update({"kernel": "ms_scan_kernel", "kernel_ms": scan_ms, "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
+        # HBM traffic of one launch of that kernel from the committed PMC passes of this same command
+        # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction applied)
+        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v3.json")
+        if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10) and os.path.exists(pmc):
+            with open(pmc) as fh:
+                roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_c2_pmc_v3.json"
         line = {
             "metric": "queries/sec (exact 128-d cosine top-k, recall@k vs brute force = %.3f)" % recall,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

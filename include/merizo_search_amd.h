@@ -72,9 +72,16 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
                const float *inv_norm, const float *lengths, const float *qlen, float mincov, float *out_scores,
                int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream);
 
-/* The two stages of ms_ip_topk for k <= 64, exposed so that a profiler / bench can time the
- * scan kernel alone: ms_ip_topk_scan runs the fused score + per-chunk top-k scan into the
- * workspace, ms_ip_topk_finish merges the per-chunk lists into the outputs. */
+/* The three stages of ms_ip_topk for k <= 64, exposed so that a profiler / bench can time the
+ * scan kernel alone.  Call them in order with identical arguments:
+ *   ms_ip_topk_prepare  queries -> padded (cosine: normalised) copy, inverse row norms if absent,
+ *                       and the sample pass (first tiles of every row stream -> a lower bound on
+ *                       each query's k-th best score);
+ *   ms_ip_topk_scan     ONE launch of the fused score + top-k scan over all rows (ms_scan_kernel);
+ *   ms_ip_topk_finish   merge of the per-stream lists into the outputs. */
+int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
+                       const float *lengths, const float *qlen, float mincov, void *workspace,
+                       size_t workspace_bytes, ms_stream_t stream);
 int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
                     const float *lengths, const float *qlen, float mincov, void *workspace, size_t workspace_bytes,
                     ms_stream_t stream);

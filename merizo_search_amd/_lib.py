@@ -11,7 +11,7 @@ import subprocess
 from typing import Optional
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmerizo_search_amd.so")
+LIB_PATH = os.environ.get("MS_LIB_OVERRIDE") or os.path.join(_PKG, "libmerizo_search_amd.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 MODE_IP_PRENORM = 0
@@ -41,6 +41,7 @@ SIGNATURES = {
     "ms_row_inv_norms": (_int, [_vp, _i64, _int, _f, _vp, _vp]),
     "ms_ip_topk_workspace_bytes": (_sz, [_i64, _int, _int]),
     "ms_ip_topk": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),

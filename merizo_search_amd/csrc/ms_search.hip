@@ -139,69 +139,16 @@ struct ScanState {
     uint32_t li[KL];
     float tau;     // scores must be > tau to matter: max(k-th best so far, floor)
     float floor;   // largest float below the sample pass's lower bound (-inf without one)
-    uint32_t qn;   // candidates appended to this query's LDS queue since the last drain (same in both lanes)
 };
 
-// Candidates that pass the filter are not inserted one by one (an insertion step is SIMD over
-// the 32 queries of the wave and would usually carry a single candidate).  They are appended to
-// small per-query queues in LDS (one ds_add_rtn + one ds_write_b64 per candidate) and the queues
-// are drained together: drain step i inserts the i-th queued candidate of EVERY query at once,
-// so a drain costs max-queue-length steps instead of total-candidates steps.
-constexpr int MS_QCAP = 16;                       // queue entries per query
-constexpr int MS_QSTRIDE = MS_QCAP + 1;            // + one dummy sink entry per query
-constexpr int MS_QBYTES = 32 * MS_QSTRIDE * 8;      // per wave
-
-// insert the pair's candidate (cs, ci) -- the same value in both lanes, -inf = none -- into
-// the pair's sorted list; general total order (score desc, row asc)
+// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
 template <int KL>
-__device__ __forceinline__ void ms_pair_insert(ScanState<KL> &st, float cs, uint32_t ci, int h) {
-    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);     // lane q+32 sees lane q's last entry
-    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
-    const bool spill = (h == 1) && ms_better(cs, ci, pl_s, pl_i);   // candidate displaces it
-    float in_s = spill ? pl_s : cs;
-    uint32_t in_i = spill ? pl_i : ci;
-    if (h == 0) { in_s = cs; in_i = ci; }
-    bool taken = false;
-#pragma unroll
-    for (int e = 0; e < KL; ++e) {
-        const bool take = taken || ms_better(in_s, in_i, st.ls[e], st.li[e]);
-        const float ts = st.ls[e];
-        const uint32_t ti = st.li[e];
-        st.ls[e] = take ? in_s : ts;
-        st.li[e] = take ? in_i : ti;
-        in_s = take ? ts : in_s;
-        in_i = take ? ti : in_i;
-        taken = take;
-    }
-    const float worst = ms_xor32_f(st.ls[KL - 1], h);     // lane q+32's last = the pair's k-th best
-    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
-}
-
-// drain all 32 queues of this wave into the register lists
-template <int KL>
-__device__ __forceinline__ void ms_queue_drain(ScanState<KL> &st, const uint2 *qbuf, int r, int h) {
-    const uint32_t cnt = st.qn < (uint32_t)MS_QCAP ? st.qn : (uint32_t)MS_QCAP;
-    for (int step = 0; step < MS_QCAP; ++step) {
-        const bool has = (uint32_t)step < cnt;
-        if (__ballot(has) == 0) break;
-        const uint2 e = qbuf[r * MS_QSTRIDE + step];         // both lanes of the pair read the same entry
-        const float s = __uint_as_float(e.x);
-        const bool live = has && (s > st.tau);               // tau may have risen since it was queued
-        ms_pair_insert<KL>(st, live ? s : -INFINITY, live ? e.y : MS_IDX_NONE, h);
-    }
-    st.qn = 0;
-}
-
-// queue the candidates of one finished tile (scores sc[16], pass masks m[16]).  Rows are
-// visited in ascending order (row 8g + 4hh + j lives in lanes of half hh, register 4g + j), so
-// whatever a mid-tile drain has already put into the lists comes from smaller rows, and the
-// strict "score > k-th best" test is the exact (score desc, row asc) order.
-template <int KL, bool STRICT>
-__device__ __forceinline__ void ms_tile_enqueue(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
-                                                int64_t sub_row0, uint2 *qbuf, int r, int h) {
+__device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
+                                               int64_t sub_row0, int r, int h) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
+        // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
@@ -209,24 +156,42 @@ __device__ __forceinline__ void ms_tile_enqueue(ScanState<KL> &st, const float (
                 const uint64_t mj = m[4 * g + j];
                 const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
                 if (mm == 0) continue;
-                const uint32_t row = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
+                const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
+                // candidate of this lane pair (or -inf); re-checked against the current tau
                 const float v = sc[4 * g + j];
-                // one candidate per query at most (lanes of half hh); both lanes of the pair track the count.
-                // STRICT: rows arrive in ascending order.  !STRICT (re-queue after an overflow drain that
-                // already holds rows of this tile): ties are kept, the drain's total-order insertion sorts them.
-                const bool mine = (h == hh) && ((mm >> r) & 1u) && (STRICT ? (v > st.tau) : (v >= st.tau));
-                if (__ballot(mine && st.qn >= (uint32_t)MS_QCAP) != 0) ms_queue_drain<KL>(st, qbuf, r, h);
-                const bool again = mine && (STRICT ? (v > st.tau) : (v >= st.tau));   // the drain may have raised tau
-                if (again) qbuf[r * MS_QSTRIDE + st.qn] = make_uint2(__float_as_uint(v), row);
-                const uint32_t inc = again ? 1u : 0u;
-                st.qn += inc + ms_xor32_u(inc, h);
+                const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
+                const float c = mine ? v : -INFINITY;
+                const float pc = ms_xor32_f(c, h);
+                const float cand = (h == hh) ? c : pc;
+                // lane q+32 receives lane q's last entry if the candidate displaces it
+                const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+                const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+                const bool spill = (h == 1) && (cand > pl_s);
+                float in_s = spill ? pl_s : cand;
+                uint32_t in_i = spill ? pl_i : crow;
+                if (h == 0) { in_s = cand; in_i = crow; }
+                bool taken = false;
+#pragma unroll
+                for (int e = 0; e < KL; ++e) {
+                    // new rows lose ties (ascending row order); a spilled entry wins them
+                    const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
+                    const float ts = st.ls[e];
+                    const uint32_t ti = st.li[e];
+                    st.ls[e] = take ? in_s : ts;
+                    st.li[e] = take ? in_i : ti;
+                    in_s = take ? ts : in_s;
+                    in_i = take ? ti : in_i;
+                    taken = take;
+                }
+                const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+                st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
             }
         }
     }
 }
 
 template <int KL, bool AUX, bool UB>
-__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
+__device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
@@ -234,7 +199,6 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
-    uint2 *qbuf = reinterpret_cast<uint2 *>(smem + 4 * 32768 + wave * MS_QBYTES);   // candidate queues
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
@@ -253,7 +217,6 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
 #pragma unroll
     for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
     st.floor = -INFINITY;
-    st.qn = 0;
 #ifdef MS_DEBUG_NO_INSERT
     st.tau = INFINITY;
 #else
@@ -264,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
         int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
         if (p.max_tiles > 0 && row_begin + (int64_t)p.max_tiles * 32 < row_end) row_end = row_begin + (int64_t)p.max_tiles * 32;
-
+        const int ntiles = (int)((row_end - row_begin + 31) / 32);
         const int qidx = qtile * 32 + r;
         const bool q_valid = qidx < p.nq;
         if (p.lb_s != nullptr) {
@@ -324,10 +287,11 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
         };
 
         // Scores of registers 4g..4g+3 of a finished tile -> sc (cosine mode: * 1/|row|, * length
-        // mask) and per-lane pass flags.  Branch-free, so it can sit between the MFMAs of the
-        // next tile.  check_rows (row < row_end) is only needed for a partial last tile.
+        // mask) and pass masks.  Branch-free so that it can sit between the MFMAs of the next
+        // tile; CHECK_ROWS (row < row_end) is only needed for the last tile of a stream, which is
+        // filtered in the drain.
         auto filter_group = [&](const f32x16 &acc, int64_t sub_row0, int g, bool check_rows, float (&sc)[16],
-                                bool (&pf)[16]) {
+                                uint64_t (&m)[16]) {
             const int64_t rbase = sub_row0 + 8 * g + 4 * h;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -348,40 +312,21 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
                     const uint32_t lrow = (uint32_t)(rbase + j);
                     pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
                 }
-                pf[4 * g + j] = pass;
+                m[4 * g + j] = __ballot(pass);
             }
         };
-        // exact, branchy path: ballot the flags and queue in ascending row order
-        auto enqueue_slow = [&](const float (&sc)[16], const bool (&pf)[16], int64_t sub_row0) {
-            uint64_t m[16];
-            uint64_t any = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { m[i] = __ballot(pf[i]); any |= m[i]; }
-            if (any != 0) ms_tile_enqueue<KL, true>(st, sc, m, sub_row0, qbuf, r, h);
-        };
 
-        const int nfull = (int)((row_end - row_begin) >> 5);       // full 32-row tiles: the pipelined loop
-        const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
-
-        // One pipeline stage = the MFMA chain of tile t (fragments in `areg`), with everything
-        // else of the neighbouring tiles folded into its gaps, all straight-line code:
-        //   * each fragment register is refilled with tile t+1 right after its 4 MFMAs issued;
-        //   * tile t-1 (scores in `prev`) is filtered, and its candidates are queued with
-        //     unconditional LDS atomics (add 0 for lanes without a candidate) and stores (to a
-        //     dummy slot for those lanes);
-        //   * the LDS-DMA of tile t+2 is issued into the slot tile t vacated.
-        // Only queue overflow and the periodic drain branch, after the chain.
+        // one pipeline stage: MFMA chain of tile t from `areg`; each fragment register is
+        // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
+        // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
         f32x4 areg[16];
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; LDS quiet
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; slot t&1 fully read
+            if (t + 2 < ntiles) issue_dma(t + 2);
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
-            const int tnext = (t + 2 < nfull) ? t + 2 : nfull - 1;           // past the end: harmless re-read
-            const char *dma_src = reinterpret_cast<const char *>(p.db) + (row_begin + (int64_t)tnext * 32) * 512;
-            f32x4 *dma_dst = slot0 + (t & 1) * 1024;
             float sc[16];
-            bool pf[16];
-            bool ovf = false;
+            uint64_t m[16];
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -393,53 +338,16 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
                 areg[tt] = src[(16 * h + tt) ^ (r & 15)];
-                if (tt >= 1 && tt < 5) filter_group(prev, prev_row0, tt - 1, false, sc, pf);
-                if (tt >= 5 && tt < 9) {
-                    // queue slots from the pair's running count (no LDS atomics), then the stores:
-                    // every lane stores, lanes without a candidate into the dummy entry.  All LDS
-                    // stores of the stage come BEFORE its LDS-DMA issues: hipcc orders a ds_write
-                    // behind every global_load_lds in flight with s_waitcnt vmcnt(0).
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int i = 4 * (tt - 5) + j;
-                        const uint32_t inc = pf[i] ? 1u : 0u;
-                        const uint32_t pinc = ms_xor32_u(inc, h);
-                        const uint32_t slot = st.qn + (h ? pinc : 0u);       // lane q before lane q+32
-                        st.qn += inc + pinc;
-                        const bool fits = slot < (uint32_t)MS_QCAP;
-                        const uint32_t row = (uint32_t)(prev_row0 + (i & 3) + 8 * (i >> 2) + 4 * h);
-                        qbuf[r * MS_QSTRIDE + ((pf[i] && fits) ? slot : (uint32_t)MS_QCAP)] = make_uint2(__float_as_uint(sc[i]), row);
-                        ovf = ovf || (pf[i] && !fits);
-                        pf[i] = pf[i] && !fits;                 // what is left for the overflow path
-                    }
-                }
-                if (tt >= 9) {                                   // the 16 DMA instructions, 3 per step
-#pragma unroll
-                    for (int u = 0; u < 3; ++u) {
-                        const int it = 3 * (tt - 9) + u;
-                        if (it < 16)
-                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + it * 1024 + off8[it & 7]),
-                                                             (__attribute__((address_space(3))) void *)(dma_dst + it * 64), 16, 0, 0);
-                    }
-                }
+                if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
             }
             out = acc;
-            if (__ballot(ovf) != 0) {            // some queue overflowed: drain, then queue the leftovers exactly
-                ms_queue_drain<KL>(st, qbuf, r, h);
-                uint64_t m[16];
+            uint64_t any = 0;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) m[i] = __ballot(pf[i]);
-                ms_tile_enqueue<KL, false>(st, sc, m, prev_row0, qbuf, r, h);
-            } else if (__ballot(st.qn >= (uint32_t)(MS_QCAP / 2)) != 0) {
-                ms_queue_drain<KL>(st, qbuf, r, h);   // keep the queues shallow and the thresholds fresh
-            }
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
         };
 
-        f32x16 last;   // scores of the tile whose candidates are not queued yet
-#pragma unroll
-        for (int i = 0; i < 16; ++i) last[i] = -INFINITY;
-        int64_t last_row0 = row_begin;
-        if (nfull > 0) {
+        if (ntiles > 0) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
@@ -447,51 +355,27 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_dma(nfull > 1 ? 1 : 0);
+            if (ntiles > 1) issue_dma(1);
             int t = 0;
-            for (; t + 1 < nfull; t += 2) {
+            for (; t + 1 < ntiles; t += 2) {
                 stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
                 stage(t + 1, acc1, acc0);   // acc1 = tile t, acc0 <- tile t+1
             }
-            if (t < nfull) {                // odd tail
+            if (t < ntiles) {               // odd tail
                 stage(t, acc0, acc1);
                 acc0 = acc1;
             }
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
-            last = acc0;
-            last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
-        }
-        {   // candidates of the last full tile (exact path; nothing passes if there was none)
+            // drain: filter + insert the last tile (scores in acc0); it may be partial
             float sc[16];
-            bool pf[16];
+            uint64_t m[16];
+            const int64_t last_row0 = row_begin + (int64_t)(ntiles - 1) * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) filter_group(last, last_row0, g, true, sc, pf);
-            enqueue_slow(sc, pf, last_row0);
+            for (int g = 0; g < 4; ++g) filter_group(acc0, last_row0, g, true, sc, m);
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, last_row0, r, h);
         }
-        if (rem > 0) {                      // partial last tile of the stream, not pipelined
-            issue_dma(nfull);               // -> slot nfull & 1, rows past the database end clamped
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
-            f32x16 acc;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-            for (int tt = 0; tt < 16; ++tt) {
-                const f32x4 a = src[(16 * h + tt) ^ (r & 15)];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-            }
-            float sc[16];
-            bool pf[16];
-            const int64_t tail_row0 = row_begin + (int64_t)nfull * 32;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) filter_group(acc, tail_row0, g, true, sc, pf);
-            enqueue_slow(sc, pf, tail_row0);
-        }
-        ms_queue_drain<KL>(st, qbuf, r, h);
     }
     const int KLc = KL;
     float (&ls)[KL] = st.ls;
@@ -549,6 +433,12 @@ __global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) {
         p.part_i[o] = v.y;
     }
 }
+
+// The full scan and the sample pass run the same body; two symbols so that profiles tell them apart.
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB>(p); }
+template <int KL, bool AUX>
+__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false>(p); }
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -711,8 +601,8 @@ int prepass_tiles_setting() {
 }
 
 int pick_kl(int k_pass) {
-    const int opts[3] = {5, 16, 32};
-    for (int i = 0; i < 3; ++i)
+    const int opts[2] = {5, 32};
+    for (int i = 0; i < 2; ++i)
         if (2 * opts[i] >= k_pass) return opts[i];
     return 32;
 }
@@ -739,7 +629,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
-    pl.lds_bytes = 4 * 32768 + 4 * MS_QBYTES;
+    pl.lds_bytes = 4 * 32768;
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     pl.prepass_tiles = prepass_tiles_setting();
@@ -775,6 +665,13 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
 
 template <int KL, bool AUX, bool UB>
 int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    if (!UB && sp.max_tiles > 0) {      // sample pass
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+        MS_LAUNCH_CHECK("ms_scan_sample_kernel");
+        return MS_OK;
+    }
     MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
@@ -782,14 +679,12 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
     return MS_OK;
 }
 
-// list width per pass: smallest of {5, 16, 32} entries per lane with 2*KL >= k of the pass
+// list width per pass: 5 entries per lane for k <= 10, else 32 (k <= 64)
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
     const bool ub = sp.ub_s != nullptr;
-    const int kl = pick_kl(sp.k);
     if (ub) return aux ? launch_scan_variant<32, true, true>(pl, sp, st) : launch_scan_variant<32, false, true>(pl, sp, st);
-    if (kl == 5) return aux ? launch_scan_variant<5, true, false>(pl, sp, st) : launch_scan_variant<5, false, false>(pl, sp, st);
-    if (kl == 16) return aux ? launch_scan_variant<16, true, false>(pl, sp, st) : launch_scan_variant<16, false, false>(pl, sp, st);
+    if (pick_kl(sp.k) == 5) return aux ? launch_scan_variant<5, true, false>(pl, sp, st) : launch_scan_variant<5, false, false>(pl, sp, st);
     return aux ? launch_scan_variant<32, true, false>(pl, sp, st) : launch_scan_variant<32, false, false>(pl, sp, st);
 }
 
@@ -801,6 +696,22 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
                        out_s, out_i, out_stride, col0, ub_s, ub_i);
     MS_LAUNCH_CHECK("ms_partial_merge_kernel");
     return MS_OK;
+}
+
+// ScanParams of the full pass from the workspace layout (queries prepared, inverse norms in the
+// workspace when the caller gave none)
+void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, const float *inv_norm, const float *lengths,
+                      const float *qlen, float mincov, char *ws, int mode, ScanParams *sp) {
+    const float *inv = inv_norm;
+    if (mode == MS_MODE_COSINE_RAW && inv == nullptr && n > 0) inv = reinterpret_cast<const float *>(ws + pl.off_inv);
+    sp->db = db; sp->n = n; sp->qn = reinterpret_cast<const float *>(ws + pl.off_qn); sp->nq = nq; sp->nq_pad = pl.nq_pad;
+    sp->k = pl.k_pass;
+    sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
+    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
+    sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
+    sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
+    sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
+    sp->qwb = pl.qwb; sp->n_qgroups = pl.n_qgroups; sp->n_sgroups = pl.n_sgroups; sp->P = pl.P;
 }
 
 // Sample pass: scan the first prepass_tiles tiles of every stream, merge, and leave the k-th
@@ -831,22 +742,14 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
     hipLaunchKernelGGL(ms_prepare_queries_kernel, dim3((pl.nq_pad + 3) / 4), dim3(256), 0, st, q, nq, pl.nq_pad,
                        mode == MS_MODE_COSINE_RAW ? 1 : 0, 1e-8f, qn);
     MS_LAUNCH_CHECK("ms_prepare_queries_kernel");
-    const float *inv = inv_norm;
-    if (mode == MS_MODE_COSINE_RAW && inv == nullptr && n > 0) {
+    if (mode == MS_MODE_COSINE_RAW && inv_norm == nullptr && n > 0) {
         float *inv_ws = reinterpret_cast<float *>(ws + pl.off_inv);
         const int64_t blocks = (n + 3) / 4;
         hipLaunchKernelGGL(ms_row_inv_norms_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
                            db, n, 1e-8f, inv_ws);
         MS_LAUNCH_CHECK("ms_row_inv_norms_kernel");
-        inv = inv_ws;
     }
-    sp->db = db; sp->n = n; sp->qn = qn; sp->nq = nq; sp->nq_pad = pl.nq_pad; sp->k = pl.k_pass;
-    sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
-    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
-    sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
-    sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
-    sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
-    sp->qwb = pl.qwb; sp->n_qgroups = pl.n_qgroups; sp->n_sgroups = pl.n_sgroups; sp->P = pl.P;
+    fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, sp);
     return MS_OK;
 }
 
@@ -892,6 +795,21 @@ size_t ms_ip_topk_workspace_bytes(int64_t n, int nq, int k) {
     return make_plan(n, nq, k, cu_count_cached()).total;
 }
 
+int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
+                       const float *lengths, const float *qlen, float mincov, void *workspace, size_t workspace_bytes,
+                       ms_stream_t stream) {
+    int rc = check_search_args(db, n, q, nq, k, mode, inv_norm, lengths, qlen);
+    if (rc) return rc;
+    if (k > 64) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prepare: k <= 64 only (use ms_ip_topk)");
+    const ScanPlan pl = make_plan(n, nq, k, cu_count_cached());
+    if (workspace == nullptr || workspace_bytes < pl.total)
+        MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_prepare: workspace %zu < %zu bytes", workspace_bytes, pl.total);
+    ScanParams sp;
+    rc = prepare_scan(pl, db, n, q, nq, mode, inv_norm, lengths, qlen, mincov, (char *)workspace, (hipStream_t)stream, &sp);
+    if (rc) return rc;
+    return run_prepass(pl, &sp, nq, (char *)workspace, (hipStream_t)stream);
+}
+
 int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
                     const float *lengths, const float *qlen, float mincov, void *workspace, size_t workspace_bytes,
                     ms_stream_t stream) {
@@ -901,11 +819,11 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     const ScanPlan pl = make_plan(n, nq, k, cu_count_cached());
     if (workspace == nullptr || workspace_bytes < pl.total)
         MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_scan: workspace %zu < %zu bytes", workspace_bytes, pl.total);
+    char *ws = (char *)workspace;
     ScanParams sp;
-    rc = prepare_scan(pl, db, n, q, nq, mode, inv_norm, lengths, qlen, mincov, (char *)workspace, (hipStream_t)stream, &sp);
-    if (rc) return rc;
-    rc = run_prepass(pl, &sp, nq, (char *)workspace, (hipStream_t)stream);
-    if (rc) return rc;
+    // same parameters as ms_ip_topk_prepare left in the workspace (queries, inverse norms, lower bound)
+    fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
+    if (pl.prepass_tiles > 0) sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
     return launch_scan(pl, sp, (hipStream_t)stream);
 }
 

@@ -77,15 +77,22 @@ def ip_topk(db, q, k: int, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=N
     return out_s, out_i
 
 
+def ip_topk_prepare(db, q, k: int, ws, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
+                    mincov: float = 0.0):
+    """Stage 1 of ip_topk (k <= 64): query preparation + sample pass."""
+    check(_lib.load().ms_ip_topk_prepare(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
+                                         ptr(qlen), mincov, ptr(ws), ws.numel(), current_stream()), "ms_ip_topk_prepare")
+
+
 def ip_topk_scan(db, q, k: int, ws, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
                  mincov: float = 0.0):
-    """Stage 1 of ip_topk (k <= 64): the fused score + top-k scan kernel only (bench timing)."""
+    """Stage 2 of ip_topk (k <= 64): the one launch of the fused score + top-k scan kernel (bench timing)."""
     check(_lib.load().ms_ip_topk_scan(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
                                       ptr(qlen), mincov, ptr(ws), ws.numel(), current_stream()), "ms_ip_topk_scan")
 
 
 def ip_topk_finish(n: int, nq: int, k: int, ws, out_s, out_i, row_offset: int = 0):
-    """Stage 2 of ip_topk (k <= 64): merge the per-chunk lists into the outputs."""
+    """Stage 3 of ip_topk (k <= 64): merge the per-stream lists into the outputs."""
     check(_lib.load().ms_ip_topk_finish(n, row_offset, nq, k, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(),
                                         current_stream()), "ms_ip_topk_finish")
 

@@ -23,12 +23,12 @@ for n, nq, k in cases:
     w = ops.TopKWorkspace(d.device); ws = w.get(n, nq, k)
     out_s = torch.empty(nq, k, device="cuda"); out_i = torch.empty(nq, k, dtype=torch.int64, device="cuda")
     for _ in range(3):
-        ops.ip_topk_scan(d, qq, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+        ops.ip_topk_prepare(d, qq, k, ws); ops.ip_topk_scan(d, qq, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     reps = 10; ts = 0.0; tm = 0.0
     for _ in range(reps):
-        e[0].record(); ops.ip_topk_scan(d, qq, k, ws); e[1].record(); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i); e[2].record()
+        e[0].record(); ops.ip_topk_prepare(d, qq, k, ws); ops.ip_topk_scan(d, qq, k, ws); e[1].record(); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i); e[2].record()
         torch.cuda.synchronize(); ts += e[0].elapsed_time(e[1]); tm += e[1].elapsed_time(e[2])
     ts /= reps; tm /= reps
     fl = 2.0 * 128 * nq * n

@@ -13,5 +13,5 @@ q = torch.randn(nq, 128, device="cuda"); q = q / q.norm(dim=1, keepdim=True)
 ws = ops.TopKWorkspace(d.device).get(n, nq, k)
 out_s = torch.empty(nq, k, device="cuda"); out_i = torch.empty(nq, k, dtype=torch.int64, device="cuda")
 for _ in range(reps):
-    ops.ip_topk_scan(d, q, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+    ops.ip_topk_prepare(d, q, k, ws); ops.ip_topk_scan(d, q, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
 torch.cuda.synchronize()

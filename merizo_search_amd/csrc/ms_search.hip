@@ -227,7 +227,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
         int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
         if (p.max_tiles > 0 && row_begin + (int64_t)p.max_tiles * 32 < row_end) row_end = row_begin + (int64_t)p.max_tiles * 32;
-        const int ntiles = (int)((row_end - row_begin + 31) / 32);
         const int qidx = qtile * 32 + r;
         const bool q_valid = qidx < p.nq;
         if (p.lb_s != nullptr) {
@@ -320,11 +319,17 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
         // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
         f32x4 areg[16];
+        const int nfull = (int)((row_end - row_begin) >> 5);       // full 32-row tiles: the pipelined loop
+        const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; slot t&1 fully read
-            if (t + 2 < ntiles) issue_dma(t + 2);
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
+            // LDS-DMA of tile t+2 (past the end: a harmless re-read of the last tile) into the slot tile t
+            // vacated, one piece per MFMA group so that its issue time hides behind the matrix pipe
+            const int tnext = (t + 2 < nfull) ? t + 2 : nfull - 1;
+            const char *dma_src = reinterpret_cast<const char *>(p.db) + (row_begin + (int64_t)tnext * 32) * 512;
+            f32x4 *dma_dst = slot0 + (t & 1) * 1024;
             float sc[16];
             uint64_t m[16];
             f32x16 acc;
@@ -335,6 +340,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 const f32x4 a = areg[tt];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
+                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
                 areg[tt] = src[(16 * h + tt) ^ (r & 15)];
@@ -347,7 +354,11 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
         };
 
-        if (ntiles > 0) {
+        f32x16 last;   // scores of the tile whose candidates are not inserted yet
+#pragma unroll
+        for (int i = 0; i < 16; ++i) last[i] = -INFINITY;
+        int64_t last_row0 = row_begin;
+        if (nfull > 0) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
@@ -355,26 +366,55 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
-            if (ntiles > 1) issue_dma(1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_dma(nfull > 1 ? 1 : 0);   // slot 1 for tile 1; with a single tile: a re-read into slot 0
             int t = 0;
-            for (; t + 1 < ntiles; t += 2) {
+            for (; t + 1 < nfull; t += 2) {
                 stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
                 stage(t + 1, acc1, acc0);   // acc1 = tile t, acc0 <- tile t+1
             }
-            if (t < ntiles) {               // odd tail
+            if (t < nfull) {                // odd tail
                 stage(t, acc0, acc1);
                 acc0 = acc1;
             }
-            // drain: filter + insert the last tile (scores in acc0); it may be partial
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
+            last = acc0;
+            last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
+        }
+        {   // filter + insert the last full tile (nothing passes if there was none)
             float sc[16];
             uint64_t m[16];
-            const int64_t last_row0 = row_begin + (int64_t)(ntiles - 1) * 32;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) filter_group(acc0, last_row0, g, true, sc, m);
+            for (int g = 0; g < 4; ++g) filter_group(last, last_row0, g, true, sc, m);
             uint64_t any = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= m[i];
             if (any != 0) ms_tile_insert<KL>(st, sc, m, last_row0, r, h);
+        }
+        if (rem > 0) {                      // partial last tile of the stream, not pipelined
+            issue_dma(nfull);               // -> slot nfull & 1; rows past the database end are clamped
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const f32x4 a = src[(16 * h + tt) ^ (r & 15)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+            }
+            float sc[16];
+            uint64_t m[16];
+            const int64_t tail_row0 = row_begin + (int64_t)nfull * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) filter_group(acc, tail_row0, g, true, sc, m);
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, tail_row0, r, h);
         }
     }
     const int KLc = KL;

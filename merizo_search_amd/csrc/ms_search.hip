@@ -142,50 +142,72 @@ struct ScanState {
 };
 
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
+// one insertion step: the candidate of row `crow` (score v in lanes of half hh whose bit is set
+// in mm) goes into the lists of all 32 queries at once
+template <int KL>
+__device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32_t mm, int hh, uint32_t crow, int r, int h) {
+    // candidate of this lane pair (or -inf); re-checked against the current tau
+    const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
+    const float c = mine ? v : -INFINITY;
+    const float pc = ms_xor32_f(c, h);
+    const float cand = (h == hh) ? c : pc;
+    // lane q+32 receives lane q's last entry if the candidate displaces it
+    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+    const bool spill = (h == 1) && (cand > pl_s);
+    float in_s = spill ? pl_s : cand;
+    uint32_t in_i = spill ? pl_i : crow;
+    if (h == 0) { in_s = cand; in_i = crow; }
+    bool taken = false;
+#pragma unroll
+    for (int e = 0; e < KL; ++e) {
+        // new rows lose ties (ascending row order); a spilled entry wins them
+        const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
+        const float ts = st.ls[e];
+        const uint32_t ti = st.li[e];
+        st.ls[e] = take ? in_s : ts;
+        st.li[e] = take ? in_i : ti;
+        in_s = take ? ts : in_s;
+        in_i = take ? ti : in_i;
+        taken = take;
+    }
+    const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+}
+
+// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]; rows in ascending
+// order: row 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 template <int KL>
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
                                                int64_t sub_row0, int r, int h) {
+    if (KL <= 8) {
+        // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
-        // rows in ascending order: row = 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
+        for (int g = 0; g < 4; ++g) {
+            if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+            for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint64_t mj = m[4 * g + j];
-                const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
-                if (mm == 0) continue;
-                const uint32_t crow = (uint32_t)(sub_row0 + 8 * g + 4 * hh + j);
-                // candidate of this lane pair (or -inf); re-checked against the current tau
-                const float v = sc[4 * g + j];
-                const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
-                const float c = mine ? v : -INFINITY;
-                const float pc = ms_xor32_f(c, h);
-                const float cand = (h == hh) ? c : pc;
-                // lane q+32 receives lane q's last entry if the candidate displaces it
-                const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
-                const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
-                const bool spill = (h == 1) && (cand > pl_s);
-                float in_s = spill ? pl_s : cand;
-                uint32_t in_i = spill ? pl_i : crow;
-                if (h == 0) { in_s = cand; in_i = crow; }
-                bool taken = false;
-#pragma unroll
-                for (int e = 0; e < KL; ++e) {
-                    // new rows lose ties (ascending row order); a spilled entry wins them
-                    const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
-                    const float ts = st.ls[e];
-                    const uint32_t ti = st.li[e];
-                    st.ls[e] = take ? in_s : ts;
-                    st.li[e] = take ? in_i : ti;
-                    in_s = take ? ts : in_s;
-                    in_i = take ? ti : in_i;
-                    taken = take;
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t mj = m[4 * g + j];
+                    const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+                    if (mm == 0) continue;
+                    ms_row_insert<KL>(st, sc[4 * g + j], mm, hh, (uint32_t)(sub_row0 + 8 * g + 4 * hh + j), r, h);
                 }
-                const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
-                st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
             }
+        }
+    } else {
+        // long lists: a single copy of the (32-slot) step inside a runtime loop over the rows keeps
+        // the code size and the build time down
+        for (int row = 0; row < 32; ++row) {
+            const int reg = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
+            uint64_t mj = m[0];
+            float v = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { mj = (reg == i) ? m[i] : mj; v = (reg == i) ? sc[i] : v; }
+            const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+            if (mm == 0) continue;
+            ms_row_insert<KL>(st, v, mm, hh, (uint32_t)(sub_row0 + row), r, h);
         }
     }
 }

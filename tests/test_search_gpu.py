@@ -208,3 +208,39 @@ def test_full_size_properties_c2(torch_gpu):
     p1 = ops.ip_topk(db[half:], q, k, row_offset=half)
     s2, i2 = ops.topk_merge(torch.stack([p0[0], p1[0]]), torch.stack([p0[1], p1[1]]))
     assert torch.equal(i2, i) and torch.equal(s2, s)
+
+
+def test_sample_prepass_is_exact_on_adversarial_order(torch_gpu):
+    """Sizes where the sample pre-pass is active (>= 32 tiles per row stream).  The sampled rows
+    (first tiles of each stream) are made UNREPRESENTATIVE: the database is sorted so that every
+    stream starts with its worst rows for query 0, plus exact duplicates straddling streams;
+    the bound from the sample must still never drop a true top-k row."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, nq, k = 160_000, 130, 10
+    db = _norm_db(n, seed=71)
+    q = _norm_db(nq, seed=72)
+    order = np.argsort(db @ q[0])                      # ascending score for query 0
+    db = np.ascontiguousarray(db[order])
+    db[150_000] = db[10]; db[77_777] = db[159_999]; db[5] = db[159_999]        # ties across streams
+    s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), k)
+    s_ref, i_ref = orc.ip_topk(db, q, k, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+def test_staged_api_equals_one_shot_and_all_equal_scores(torch_gpu):
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    n, nq, k = 150_000, 64, 7
+    db = np.tile(_norm_db(1, seed=5), (n, 1))          # every row identical: every score ties
+    q = _norm_db(nq, seed=6)
+    d_db, d_q = _dev(torch, db), _dev(torch, q)
+    s, i = ops.ip_topk(d_db, d_q, k)
+    assert (i.cpu().numpy() == np.arange(k)[None, :]).all()      # ties -> lowest rows
+    ws = ops.TopKWorkspace(d_db.device).get(n, nq, k)
+    out_s = torch.empty((nq, k), dtype=torch.float32, device="cuda")
+    out_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
+    ops.ip_topk_prepare(d_db, d_q, k, ws); ops.ip_topk_scan(d_db, d_q, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i, row_offset=42)
+    assert torch.equal(out_s, s) and torch.equal(out_i, i + 42)

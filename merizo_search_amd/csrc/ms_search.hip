@@ -221,6 +221,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
+    // cosine mode: 1/|row| (32 floats) + target lengths (32 floats) of a tile, 4 slots (tile index & 3)
+    float *aux0 = reinterpret_cast<float *>(smem + 4 * 32768 + wave * 1024);
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
@@ -284,7 +286,18 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         uint32_t off8[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) off8[c] = (uint32_t)(h * 512 + 16 * ((r ^ h) ^ (2 * c)));
+        // cosine mode: one more LDS-DMA piece per tile (4 B per lane): lanes 0-31 fetch 1/|row| of the
+        // tile's rows, lanes 32-63 their lengths (clamped to the last database row), into aux slot t & 3
+        auto issue_aux_dma = [&](int t) {
+            if (!AUX) return;
+            int64_t row = row_begin + (int64_t)t * 32 + r;
+            if (row >= p.n) row = p.n - 1;
+            const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + row),
+                                             (__attribute__((address_space(3))) void *)(aux0 + (t & 3) * 64), 4, 0, 0);
+        };
         auto issue_dma = [&](int t) {
+            issue_aux_dma(t);
             const int64_t row0 = row_begin + (int64_t)t * 32;
             f32x4 *dst = slot0 + (t & 1) * 1024;
             const char *tile_src = reinterpret_cast<const char *>(p.db) + row0 * 512;
@@ -318,13 +331,16 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             for (int j = 0; j < 4; ++j) {
                 float s = acc[4 * g + j];
                 if (AUX) {
-                    int64_t ri = rbase + j;                       // clamped: always a valid row of this stream
-                    ri = ri < row_begin ? row_begin : (ri >= row_end ? row_end - 1 : ri);
-                    if (p.inv_norm != nullptr) s = s * p.inv_norm[ri];
+                    // tile index from its first row; before the first tile (sub_row0 < row_begin, scores
+                    // are -inf) any slot will do
+                    const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
+                    const float *ax = aux0 + tix * 64 + 8 * g + 4 * h + j;
+                    float sv = s * ax[0];                                                        // 1 / max(|row|, 1e-8)
                     if (p.lengths != nullptr) {
-                        const float mk = (my_qlen >= p.lengths[ri] * p.mincov) ? 1.0f : 0.0f;   // dbsearch.py:76
-                        s = s * mk;                                                              // dbsearch.py:78
+                        const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;           // dbsearch.py:76
+                        sv = sv * mk;                                                            // dbsearch.py:78
                     }
+                    s = (sub_row0 >= row_begin) ? sv : -INFINITY;   // "tile -1" of the pipeline has no aux data
                 }
                 sc[4 * g + j] = s;
                 bool pass = q_valid && (s > st.tau);
@@ -364,6 +380,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
                                                  (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
+                if (tt == 15) issue_aux_dma(tnext);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
                 areg[tt] = src[(16 * h + tt) ^ (r & 15)];
@@ -403,7 +420,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             last = acc0;
             last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
         }
-        {   // filter + insert the last full tile (nothing passes if there was none)
+        if (nfull > 0) {   // filter + insert the last full tile
             float sc[16];
             uint64_t m[16];
 #pragma unroll
@@ -691,11 +708,12 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
-    pl.lds_bytes = 4 * 32768;
+    pl.lds_bytes = 4 * 32768 + 4 * 1024;
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     pl.prepass_tiles = prepass_tiles_setting();
-    if (tiles_per_stream < 16 * (int64_t)pl.prepass_tiles || k > 64) pl.prepass_tiles = 0;
+    if (tiles_per_stream < 16 * (int64_t)pl.prepass_tiles && pl.prepass_tiles > 1) pl.prepass_tiles = 1;   // short streams: one tile
+    if (tiles_per_stream < 12 * (int64_t)pl.prepass_tiles || k > 64 || nq < 16) pl.prepass_tiles = 0;   // few queries: few insertions anyway
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);

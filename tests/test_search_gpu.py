@@ -244,3 +244,21 @@ def test_staged_api_equals_one_shot_and_all_equal_scores(torch_gpu):
     out_i = torch.empty((nq, k), dtype=torch.int64, device="cuda")
     ops.ip_topk_prepare(d_db, d_q, k, ws); ops.ip_topk_scan(d_db, d_q, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i, row_offset=42)
     assert torch.equal(out_s, s) and torch.equal(out_i, i + 42)
+
+
+@pytest.mark.parametrize("n", [10, 33, 42, 70, 1000])
+def test_cosine_tiny_databases_partial_tiles(n, torch_gpu):
+    """Streams shorter than one tile / with a partial tail in cosine mode (regression: scores of a
+    non-existent pipeline tile scaled by uninitialised LDS)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    db, lengths = syn.raw_database(n, seed=90 + n)
+    q, qlen = syn.raw_queries(5, seed=91)
+    junk = torch.full((64 << 20,), float("nan"), device="cuda"); del junk       # dirty the allocator's memory
+    for _ in range(3):
+        s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), min(5, n), mode=ops.MODE_COSINE_RAW,
+                           lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
+        s_ref, i_ref = orc.cosine_topk(db, q, min(5, n), lengths, qlen, 0.7)
+        assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)

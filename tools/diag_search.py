@@ -17,18 +17,23 @@ for order in (0, 1):
 cases = ((1_000_000, 256, 10), (1_000_000, 32, 10), (1_000_000, 1, 10), (4_000_000, 256, 10), (1_000_000, 1024, 10))
 if len(sys.argv) > 1:
     cases = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+aux = os.environ.get('DIAG_COSINE') == '1'
 for n, nq, k in cases:
-    d = syn.device_database(n, 0, 0, "cuda:0")
+    d = syn.device_database(n, 0, 0, "cuda:0", normalize=not aux)
+    kw = {}
+    if aux:
+        kw = dict(mode=ops.MODE_COSINE_RAW, inv_norm=ops.row_inv_norms(d), lengths=torch.from_numpy(syn.ted_lengths(n, 3).astype(np.float32)).cuda(),
+                  qlen=torch.from_numpy(syn.ted_lengths(nq, 4).astype(np.float32)).cuda(), mincov=0.7)
     qq = torch.randn(nq, 128, device="cuda"); qq = qq / qq.norm(dim=1, keepdim=True)
     w = ops.TopKWorkspace(d.device); ws = w.get(n, nq, k)
     out_s = torch.empty(nq, k, device="cuda"); out_i = torch.empty(nq, k, dtype=torch.int64, device="cuda")
     for _ in range(3):
-        ops.ip_topk_prepare(d, qq, k, ws); ops.ip_topk_scan(d, qq, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+        ops.ip_topk_prepare(d, qq, k, ws, **kw); ops.ip_topk_scan(d, qq, k, ws, **kw); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     reps = 10; ts = 0.0; tm = 0.0
     for _ in range(reps):
-        e[0].record(); ops.ip_topk_prepare(d, qq, k, ws); ops.ip_topk_scan(d, qq, k, ws); e[1].record(); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i); e[2].record()
+        e[0].record(); ops.ip_topk_prepare(d, qq, k, ws, **kw); ops.ip_topk_scan(d, qq, k, ws, **kw); e[1].record(); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i); e[2].record()
         torch.cuda.synchronize(); ts += e[0].elapsed_time(e[1]); tm += e[1].elapsed_time(e[2])
     ts /= reps; tm /= reps
     fl = 2.0 * 128 * nq * n

@@ -360,7 +360,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const int nfull = (int)((row_end - row_begin) >> 5);       // full 32-row tiles: the pipelined loop
         const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // tile t+1 landed; slot t&1 fully read
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot t&1 (tile t) fully read into areg
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
             // LDS-DMA of tile t+2 (past the end: a harmless re-read of the last tile) into the slot tile t
@@ -378,12 +378,19 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 const f32x4 a = areg[tt];
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                // tile t+1 was issued during the previous chain: it only has to have landed by the middle
+                // of this one.  vmcnt(8): everything but the 8 pieces of tile t+2 issued so far.
+                if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
                                                  (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
                 if (tt == 15) issue_aux_dma(tnext);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-                areg[tt] = src[(16 * h + tt) ^ (r & 15)];
+                if (tt >= 8) {   // refill the fragment registers of groups 2(tt-8), 2(tt-8)+1 (already consumed) with tile t+1
+                    const int f0 = 2 * (tt - 8);
+                    areg[f0] = src[(16 * h + f0) ^ (r & 15)];
+                    areg[f0 + 1] = src[(16 * h + f0 + 1) ^ (r & 15)];
+                }
                 if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
             }
             out = acc;
@@ -673,7 +680,7 @@ int prepass_tiles_setting() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("MS_PREPASS_TILES");
-        v = e ? atoi(e) : 2;
+        v = e ? atoi(e) : 4;
         if (v < 0) v = 0;
     }
     return v;
@@ -712,7 +719,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     pl.prepass_tiles = prepass_tiles_setting();
-    if (tiles_per_stream < 16 * (int64_t)pl.prepass_tiles && pl.prepass_tiles > 1) pl.prepass_tiles = 1;   // short streams: one tile
+    while (pl.prepass_tiles > 1 && tiles_per_stream < 16 * (int64_t)pl.prepass_tiles) pl.prepass_tiles /= 2;   // shorter streams: smaller sample
     if (tiles_per_stream < 12 * (int64_t)pl.prepass_tiles || k > 64 || nq < 16) pl.prepass_tiles = 0;   // few queries: few insertions anyway
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);

@@ -212,7 +212,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
     }
 }
 
-template <int KL, bool AUX, bool UB>
+template <int KL, bool AUX, bool UB, bool SHARE>
 __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -220,7 +220,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     // below becomes 64-bit per-lane arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);   // this wave's two 32 x 32 float4 slots
+    // two 32 x 32 float4 tile slots: per workgroup when the 4 waves scan the same rows (SHARE), else per wave
+    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + (SHARE ? 0 : wave * 32768));
     // cosine mode: 1/|row| (32 floats) + target lengths (32 floats) of a tile, 4 slots (tile index & 3)
     float *aux0 = reinterpret_cast<float *>(smem + 4 * 32768 + wave * 1024);
 
@@ -235,7 +236,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     const int qw = wave % p.qwb, sw = wave / p.qwb;
     const int stream = sgroup * spb + sw;
     const int qtile = qg * p.qwb + qw;
-    const bool active = stream < p.n_streams && qtile < p.n_qtiles;
+    // SHARE: a wave whose query tile is padding still issues its DMA pieces and joins the barriers
+    const bool active = stream < p.n_streams && (SHARE || qtile < p.n_qtiles);
 
     ScanState<KL> st;
 #pragma unroll
@@ -304,6 +306,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (row0 + 32 <= p.n) {
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
+                    if (SHARE && (it >> 2) != wave) continue;        // this wave's quarter of the pieces
                     const char *src = tile_src + it * 1024 + off8[it & 7];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                      (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
@@ -311,6 +314,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
+                    if (SHARE && (it >> 2) != wave) continue;
                     int64_t row = row0 + 2 * it + h;
                     if (row >= p.n) row = p.n - 1;
                     const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
@@ -361,6 +365,11 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot t&1 (tile t) fully read into areg
+            if (SHARE) {
+                // everybody has read tile t out of the slot about to be refilled, and (second barrier,
+                // mid-chain) everybody's pieces of tile t+1 have landed
+                __builtin_amdgcn_s_barrier();
+            }
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
             // LDS-DMA of tile t+2 (past the end: a harmless re-read of the last tile) into the slot tile t
@@ -380,9 +389,21 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
                 // tile t+1 was issued during the previous chain: it only has to have landed by the middle
                 // of this one.  vmcnt(8): everything but the 8 pieces of tile t+2 issued so far.
-                if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
-                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
+                if (!SHARE) {
+                    if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
+                                                     (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
+                } else {
+                    if (tt < 4) {          // this wave's 4 pieces of tile t+2
+                        const int it = 4 * wave + tt;
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + it * 1024 + off8[it & 7]),
+                                                         (__attribute__((address_space(3))) void *)(dma_dst + it * 64), 16, 0, 0);
+                    }
+                    if (tt == 8) {         // own pieces of tile t+1 landed (all but the 4 just issued), then everybody's
+                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                    }
+                }
                 if (tt == 15) issue_aux_dma(tnext);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
@@ -410,10 +431,11 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
             issue_dma(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SHARE) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_dma(nfull > 1 ? 1 : 0);   // slot 1 for tile 1; with a single tile: a re-read into slot 0
+            issue_dma(1 < nfull ? 1 : 1);   // always into slot 1 (SHARE: slower waves may still read slot 0); tile 1 may be past the end: clamped reads, never used
             int t = 0;
             for (; t + 1 < nfull; t += 2) {
                 stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
@@ -424,6 +446,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 acc0 = acc1;
             }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
+            if (SHARE) __builtin_amdgcn_s_barrier();
             last = acc0;
             last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
         }
@@ -440,6 +463,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         if (rem > 0) {                      // partial last tile of the stream, not pipelined
             issue_dma(nfull);               // -> slot nfull & 1; rows past the database end are clamped
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (SHARE) __builtin_amdgcn_s_barrier();
             const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
             f32x16 acc;
 #pragma unroll
@@ -521,10 +545,10 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 }
 
 // The full scan and the sample pass run the same body; two symbols so that profiles tell them apart.
-template <int KL, bool AUX, bool UB>
-__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB>(p); }
-template <int KL, bool AUX>
-__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false>(p); }
+template <int KL, bool AUX, bool UB, bool SHARE>
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB, SHARE>(p); }
+template <int KL, bool AUX, bool SHARE>
+__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false, SHARE>(p); }
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -676,6 +700,12 @@ int cu_count_cached() {
     return cus;
 }
 
+int share_tiles_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_SHARE_TILES"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 int prepass_tiles_setting() {
     static int v = -1;
     if (v < 0) {
@@ -750,29 +780,35 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     return MS_OK;
 }
 
-template <int KL, bool AUX, bool UB>
+template <int KL, bool AUX, bool UB, bool SHARE>
 int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     if (!UB && sp.max_tiles > 0) {      // sample pass
-        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX>),
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX, SHARE>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX, SHARE>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB, SHARE>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB, SHARE>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
     MS_LAUNCH_CHECK("ms_scan_kernel");
     return MS_OK;
 }
 
+template <int KL, bool UB>
+int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
+    const bool share = sp.qwb == 4 && share_tiles_setting();
+    if (aux) return share ? launch_scan_variant<KL, true, UB, true>(pl, sp, st) : launch_scan_variant<KL, true, UB, false>(pl, sp, st);
+    return share ? launch_scan_variant<KL, false, UB, true>(pl, sp, st) : launch_scan_variant<KL, false, UB, false>(pl, sp, st);
+}
+
 // list width per pass: 5 entries per lane for k <= 10, else 32 (k <= 64)
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
-    const bool ub = sp.ub_s != nullptr;
-    if (ub) return aux ? launch_scan_variant<32, true, true>(pl, sp, st) : launch_scan_variant<32, false, true>(pl, sp, st);
-    if (pick_kl(sp.k) == 5) return aux ? launch_scan_variant<5, true, false>(pl, sp, st) : launch_scan_variant<5, false, false>(pl, sp, st);
-    return aux ? launch_scan_variant<32, true, false>(pl, sp, st) : launch_scan_variant<32, false, false>(pl, sp, st);
+    if (sp.ub_s != nullptr) return launch_scan_kl<32, true>(pl, sp, st);
+    if (pick_kl(sp.k) == 5) return launch_scan_kl<5, false>(pl, sp, st);
+    return launch_scan_kl<32, false>(pl, sp, st);
 }
 
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,

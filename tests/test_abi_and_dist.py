@@ -111,3 +111,35 @@ def test_sharded_search_two_ranks_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert f"rank {r} ok" in o
+
+
+def test_c_abi_argument_errors_are_reported_without_a_gpu():
+    """Bad arguments are rejected by the host-side checks (no kernel launch): error code + message."""
+    import ctypes
+    from merizo_search_amd import _lib
+    lib = _lib.load()
+    rc = lib.ms_ip_topk(None, -1, 0, None, 1, 1, 0, None, None, None, 0.0, None, None, None, 0, None)
+    assert rc == -1 and b"n >= 0" in lib.ms_last_error()
+    rc = lib.ms_ip_topk(None, 0, 0, ctypes.c_void_p(16), 1, 1, 7, None, None, None, 0.0, None, None, None, 0, None)
+    assert rc == -1 and b"unknown mode" in lib.ms_last_error()
+    rc = lib.ms_ip_topk(ctypes.c_void_p(16), 2 ** 31, 0, ctypes.c_void_p(16), 1, 1, 0, None, None, None, 0.0, None, None, None, 0, None)
+    assert rc == -4 and b"shard the database" in lib.ms_last_error()
+    rc = lib.ms_ip_topk(ctypes.c_void_p(16), 10, 0, ctypes.c_void_p(16), 1, 1, 0, ctypes.c_void_p(16), None, None, 0.0,
+                        ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
+    assert rc == -1 and b"only valid in MS_MODE_COSINE_RAW" in lib.ms_last_error()
+    rc = lib.ms_ip_topk(ctypes.c_void_p(16), 10, 0, ctypes.c_void_p(16), 1, 1, 0, None, None, None, 0.0,
+                        ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
+    assert rc == -2 and b"workspace" in lib.ms_last_error()
+    rc = lib.ms_l2_normalize_rows(ctypes.c_void_p(16), 4, 64, 1e-12, None)
+    assert rc == -1 and b"d must be 128" in lib.ms_last_error()
+    rc = lib.ms_topk_merge(None, None, 0, 1, 1, None, None, None)
+    assert rc == -1
+    import numpy as np
+    offs = np.array([0, 5, 5], dtype=np.int32)
+    rc = lib.ms_egnn_embed(ctypes.c_void_p(16), ctypes.c_void_p(16), 3000, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                           offs.ctypes.data, 2, ctypes.c_void_p(16), None, 0, None)
+    assert rc == -1 and b"is empty" in lib.ms_last_error()
+    offs = np.array([0, 3001], dtype=np.int32)
+    rc = lib.ms_egnn_embed(ctypes.c_void_p(16), ctypes.c_void_p(16), 3000, ctypes.c_void_p(16), ctypes.c_void_p(16),
+                           offs.ctypes.data, 1, ctypes.c_void_p(16), None, 0, None)
+    assert rc == -4 and b"positional table" in lib.ms_last_error()

@@ -100,6 +100,8 @@ struct ScanParams {
     const uint32_t *ub_i;
     const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
     int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
+    int first_tile;         // > 0 (loader-wave form only): the first tiles of every stream were scanned by the sample
+                            // pass; start from its lists (still in part_s / part_i) at this tile
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
     int rows_per_stream;    // multiple of 32
@@ -109,6 +111,9 @@ struct ScanParams {
     int n_qgroups;
     int n_sgroups;          // stream groups = workgroups per query group
     int P;                  // partial lists per query written by this launch
+#ifdef MS_STAMP
+    unsigned long long *stamps;   // diagnostic builds only: per compute wave {cycles, 100 MHz ticks, tiles, 0}
+#endif
 };
 
 // value of `x` in the partner lane (lane ^ 32): one v_permlane32_swap + one select, no LDS
@@ -212,7 +217,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
     }
 }
 
-template <int KL, bool AUX, bool UB, bool SHARE>
+template <int KL, bool AUX, bool UB>
 __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -220,8 +225,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     // below becomes 64-bit per-lane arithmetic
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    // two 32 x 32 float4 tile slots: per workgroup when the 4 waves scan the same rows (SHARE), else per wave
-    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + (SHARE ? 0 : wave * 32768));
+    // two private 32 x 32 float4 tile slots per wave
+    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);
     // cosine mode: 1/|row| (32 floats) + target lengths (32 floats) of a tile, 4 slots (tile index & 3)
     float *aux0 = reinterpret_cast<float *>(smem + 4 * 32768 + wave * 1024);
 
@@ -236,8 +241,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     const int qw = wave % p.qwb, sw = wave / p.qwb;
     const int stream = sgroup * spb + sw;
     const int qtile = qg * p.qwb + qw;
-    // SHARE: a wave whose query tile is padding still issues its DMA pieces and joins the barriers
-    const bool active = stream < p.n_streams && (SHARE || qtile < p.n_qtiles);
+    const bool active = stream < p.n_streams && qtile < p.n_qtiles;
 
     ScanState<KL> st;
 #pragma unroll
@@ -264,6 +268,8 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             st.tau = st.floor;
 #endif
         }
+        // padding queries of the last tile never pass the filter: threshold +inf (one compare per score)
+        if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }
 
         // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
         float qreg[64];
@@ -306,7 +312,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (row0 + 32 <= p.n) {
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
-                    if (SHARE && (it >> 2) != wave) continue;        // this wave's quarter of the pieces
                     const char *src = tile_src + it * 1024 + off8[it & 7];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                                      (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
@@ -314,7 +319,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
 #pragma unroll
                 for (int it = 0; it < 16; ++it) {
-                    if (SHARE && (it >> 2) != wave) continue;
                     int64_t row = row0 + 2 * it + h;
                     if (row >= p.n) row = p.n - 1;
                     const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
@@ -347,7 +351,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                     s = (sub_row0 >= row_begin) ? sv : -INFINITY;   // "tile -1" of the pipeline has no aux data
                 }
                 sc[4 * g + j] = s;
-                bool pass = q_valid && (s > st.tau);
+                bool pass = s > st.tau;
                 if (check_rows) pass = pass && (rbase + j < row_end);
                 if (UB) {
                     const uint32_t lrow = (uint32_t)(rbase + j);
@@ -365,11 +369,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
         auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot t&1 (tile t) fully read into areg
-            if (SHARE) {
-                // everybody has read tile t out of the slot about to be refilled, and (second barrier,
-                // mid-chain) everybody's pieces of tile t+1 have landed
-                __builtin_amdgcn_s_barrier();
-            }
             const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
             const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
             // LDS-DMA of tile t+2 (past the end: a harmless re-read of the last tile) into the slot tile t
@@ -389,21 +388,9 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
                 // tile t+1 was issued during the previous chain: it only has to have landed by the middle
                 // of this one.  vmcnt(8): everything but the 8 pieces of tile t+2 issued so far.
-                if (!SHARE) {
-                    if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
-                                                     (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
-                } else {
-                    if (tt < 4) {          // this wave's 4 pieces of tile t+2
-                        const int it = 4 * wave + tt;
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + it * 1024 + off8[it & 7]),
-                                                         (__attribute__((address_space(3))) void *)(dma_dst + it * 64), 16, 0, 0);
-                    }
-                    if (tt == 8) {         // own pieces of tile t+1 landed (all but the 4 just issued), then everybody's
-                        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                        __builtin_amdgcn_s_barrier();
-                    }
-                }
+                if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
+                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
                 if (tt == 15) issue_aux_dma(tnext);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
@@ -431,11 +418,10 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
             issue_dma(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (SHARE) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_dma(1 < nfull ? 1 : 1);   // always into slot 1 (SHARE: slower waves may still read slot 0); tile 1 may be past the end: clamped reads, never used
+            issue_dma(1);                   // into slot 1; tile 1 may be past the end: clamped reads, never used
             int t = 0;
             for (; t + 1 < nfull; t += 2) {
                 stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
@@ -446,7 +432,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 acc0 = acc1;
             }
             asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
-            if (SHARE) __builtin_amdgcn_s_barrier();
             last = acc0;
             last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
         }
@@ -463,7 +448,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         if (rem > 0) {                      // partial last tile of the stream, not pipelined
             issue_dma(nfull);               // -> slot nfull & 1; rows past the database end are clamped
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (SHARE) __builtin_amdgcn_s_barrier();
             const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
             f32x16 acc;
 #pragma unroll
@@ -544,11 +528,382 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     }
 }
 
+// ------------------------------------------------------------------ scan, loader-wave form
+// MFMA-bound batches (>= 3 query tiles, qwb == 4): the 4 compute waves of a workgroup scan the
+// SAME rows for 4 query tiles.  In ms_scan_body each of them fetches its own copy of every tile,
+// and the 16 LDS-DMA pieces per tile cost the issuing wave about 60 cycles each inside its MFMA
+// chain (4.1k -> 5.2k cycles per tile, in-kernel stamps).  Here a FIFTH wave does nothing but the
+// LDS-DMA: one copy of each tile into a ring of LDR_R slots shared by the workgroup, up to
+// LDR_D tiles in flight (counted s_waitcnt vmcnt), published through flag words in LDS; the
+// compute waves poll the flag of tile t+1 in the middle of chain t and report what they have
+// consumed.  No barrier: a wave delayed by insertions may trail the others by LDR_R - 1 tiles
+// before the loader has to wait for it.  (The kernel needs <= 256 registers per wave so that
+// the loader can share a SIMD with a compute wave: __launch_bounds__(320, 2).)
+constexpr int LDR_R = 4;        // ring slots (tiles)
+constexpr int LDR_D = 3;        // tiles the loader keeps in flight before publishing the oldest
+constexpr int LDR_AUX = 8;      // aux (row scale / length) ring: a tile's aux data outlives its slot by two stages
+constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
+
+// LDS-DMA pieces as inline asm (the loader wave sets M0 itself; nothing else in that wave uses M0):
+// 64 lanes x 16 B (or 4 B) from global memory to LDS bytes lds_addr + lane * size.
+__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void ms_glds_v16(uint32_t lds_addr, const void *lane_ptr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+}
+__device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+}
+
+template <bool AUX, int N>
+__device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N tiles' worth of DMA pieces are in flight
+    constexpr int P = AUX ? 17 : 16;
+    if (N * P == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N * P == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N * P == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else if (N * P == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (N * P == 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 compute, 4 loader
+    const int r = lane & 31, h = lane >> 5;
+    f32x4 *ring = reinterpret_cast<f32x4 *>(smem);                                    // LDR_R x (32 x 32 float4)
+    float *auxring = reinterpret_cast<float *>(smem + LDR_R * 16384);                 // LDR_AUX x 64 floats
+    // flag words, as explicit LDS (address space 3) pointers: a volatile access through a generic
+    // pointer compiles to flat_load + s_waitcnt vmcnt(0), hundreds of cycles in the middle of a chain
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
+    lds_flag_t *full = (lds_flag_t *)(smem + LDR_R * 16384 + LDR_AUX * 256);          // [LDR_R] tile+1 held by the slot
+    lds_flag_t *consumed = full + 8;                                                   // [4] tiles read by compute wave w
+
+    const int bid = blockIdx.x;
+    const int per_super = 8 * p.n_qgroups;
+    const int super = bid / per_super, within = bid % per_super;
+    const int stream = super * 8 + (within & 7);      // qwb == 4: one stream per workgroup
+    const int qg = within >> 3;
+    if (stream >= p.n_streams) return;
+    const int64_t stream_begin = (int64_t)stream * p.rows_per_stream;
+    const int64_t row_end = (stream_begin + p.rows_per_stream < p.n) ? stream_begin + p.rows_per_stream : p.n;
+    // resume: rows before first_tile are already in the lists the sample pass left behind
+    int64_t row_begin = stream_begin + (int64_t)p.first_tile * 32;
+    if (row_begin > row_end) row_begin = row_end;
+    const int nfull = (int)((row_end - row_begin) >> 5);
+    const int rem = (int)((row_end - row_begin) & 31);
+    const int ntl = nfull + (rem > 0 ? 1 : 0);        // tiles the loader delivers (the last one may be partial)
+
+    if (tid < 16) {
+        uint32_t v = 0;
+        if (tid >= 8 && tid < 12) v = ((qg * 4 + (tid - 8)) < p.n_qtiles) ? 0u : 0xFFFFFFFFu;   // padding query tiles never block the loader
+        full[tid] = v;
+    }
+    __syncthreads();
+
+    if (wave == 4) {
+        // ---------------- loader ----------------
+#ifdef MS_ABL_NOFLAG
+        if (lane == 0) for (int i = 0; i < LDR_R; ++i) full[i] = 0x7FFFFFFFu;
+        return;
+#endif
+        // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs
+        // back to back, so it is written to need as few instructions as possible: raised priority,
+        // and every LDS-DMA piece is one s_mov m0 + one global_load_lds with an SGPR base and a
+        // precomputed 32-bit lane offset (inline asm: hipcc's builtin form spends 2-5 VALU
+        // instructions per piece on 64-bit lane addresses).
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t voff[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) voff[it] = (uint32_t)(it * 1024 + h * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
+        const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
+        const uint32_t aux_lds = ring_lds + LDR_R * 16384;
+#ifdef MS_STAMP
+        unsigned long long lst_poll = 0, lst_issue = 0, lst_vm = 0, lst_t0 = __builtin_amdgcn_s_memtime();
+#define LST(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - lst_t0; lst_t0 = now_; }
+#else
+#define LST(acc)
+#endif
+        for (int t = 0; t < ntl; ++t) {
+            if (t >= LDR_R) {                          // slot t % R is free once everybody has read tile t - R
+                const uint32_t need = (uint32_t)(t - LDR_R + 1);
+                for (uint32_t spins = 0;; ++spins) {
+                    const uint32_t c0 = consumed[0], c1 = consumed[1], c2 = consumed[2], c3 = consumed[3];
+                    const uint32_t m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
+                    if (__builtin_amdgcn_readfirstlane(m01 < m23 ? m01 : m23) >= need) break;
+                    if (spins > (1u << 24)) __builtin_trap();     // never a silent hang
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            LST(lst_poll)
+            const int64_t row0 = row_begin + (int64_t)t * 32;
+            const uint32_t slot_lds = ring_lds + (uint32_t)(t % LDR_R) * 16384u;
+            if (AUX) {
+                int64_t row = row0 + r;
+                if (row >= p.n) row = p.n - 1;
+                const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+                ms_glds_v4(aux_lds + (uint32_t)(t % LDR_AUX) * 256u, base + row);
+            }
+            if (row0 + 32 <= p.n) {
+                const uint64_t b = (uint64_t)(uintptr_t)p.db + (uint64_t)row0 * 512u;
+                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);        // (the builtin returns int:
+                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));  //  no sign extension)
+                const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) ms_glds_s16(slot_lds + it * 1024, voff[it], sb);
+            } else {       // last tile of the database: clamp rows past the end (their scores are discarded)
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    int64_t row = row0 + 2 * it + h;
+                    if (row >= p.n) row = p.n - 1;
+                    ms_glds_v16(slot_lds + it * 1024,
+                                reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
+                }
+            }
+            LST(lst_issue)
+            if (t >= LDR_D - 1) {                      // tile t - (D-1) has landed: publish it
+                ms_vmcnt_tiles<AUX, LDR_D - 1>();
+                const int tp = t - (LDR_D - 1);
+                if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+            }
+            LST(lst_vm)
+        }
+#ifdef MS_STAMP
+        if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 32 + 32 <= 4 * 4 * 65536) {
+            unsigned long long *o = p.stamps + ((size_t)bid * 8 + 4) * 4;
+            o[0] = lst_poll; o[1] = lst_issue; o[2] = lst_vm; o[3] = (unsigned long long)ntl;
+        }
+#endif
+        // drain: publish the last D-1 tiles
+        if (ntl >= 2) {
+            ms_vmcnt_tiles<AUX, 1>();
+            const int tp = ntl - 2;
+            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+        }
+        if (ntl >= 1) {
+            ms_vmcnt_tiles<AUX, 0>();
+            const int tp = ntl - 1;
+            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    const int qtile = qg * 4 + wave;
+    if (qtile >= p.n_qtiles) return;
+    ScanState<KL> st;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+    st.floor = -INFINITY;
+#ifdef MS_DEBUG_NO_INSERT
+    st.tau = INFINITY;
+#else
+    st.tau = -INFINITY;
+#endif
+    const int qidx = qtile * 32 + r;
+    const bool q_valid = qidx < p.nq;
+    if (p.lb_s != nullptr) {
+        const float lb = p.lb_s[qidx];
+        st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
+#ifndef MS_DEBUG_NO_INSERT
+        st.tau = st.floor;
+#endif
+    }
+    if (p.first_tile > 0) {
+        // the lists of this (stream, query) as the sample pass wrote them: ranks h*KL .. h*KL+KL-1 of the lane pair
+#pragma unroll
+        for (int j = 0; j < KL; ++j) {
+            const int rank = h * KL + j;
+            if (rank < p.k) {
+                const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+                st.ls[j] = p.part_s[o];
+                st.li[j] = p.part_i[o];
+            }
+        }
+#ifndef MS_DEBUG_NO_INSERT
+        const float worst = ms_xor32_f(st.ls[KL - 1], h);           // lane q+32's last entry = the pair's worst
+        st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+#endif
+    }
+    if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
+    float qreg[64];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 v = src[t];
+            qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+        }
+    }
+    float my_qlen = 0.0f;
+    if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+    float ubs = INFINITY;
+    uint32_t ubi = 0;
+    if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
+
+    auto wait_tile = [&](int t) {          // until the loader has published tile t
+        const uint32_t need = (uint32_t)(t + 1);
+        for (uint32_t spins = 0; __builtin_amdgcn_readfirstlane(full[t % LDR_R]) < need; ++spins) {
+            if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto filter_group = [&](const f32x16 &acc, int t, int g, bool check_rows, float (&sc)[16], uint64_t (&m)[16]) {
+        const int64_t sub_row0 = row_begin + (int64_t)t * 32;
+        const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[4 * g + j];
+            if (AUX) {
+                const float *ax = auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h + j;
+                float sv = s * ax[0];                                                        // 1 / max(|row|, 1e-8)
+                if (p.lengths != nullptr) {
+                    const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;           // dbsearch.py:76
+                    sv = sv * mk;                                                            // dbsearch.py:78
+                }
+                s = (t >= 0) ? sv : -INFINITY;     // "tile -1" of the pipeline has no aux data
+            }
+            sc[4 * g + j] = s;
+            bool pass = s > st.tau;
+            if (check_rows) pass = pass && (rbase + j < row_end);
+            if (UB) {
+                const uint32_t lrow = (uint32_t)(rbase + j);
+                pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
+            }
+            m[4 * g + j] = __ballot(pass);
+        }
+    };
+
+    f32x4 areg[16];
+#ifdef MS_STAMP
+    unsigned long long stamp_wait = 0, stamp_nwait = 0;
+#endif
+    auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
+#ifndef MS_ABL_NOFLAG
+        if (lane == 0) consumed[wave] = (uint32_t)(t + 1);
+#endif
+        const f32x4 *src = ring + ((t + 1) % LDR_R) * 1024 + r * 32;
+        float sc[16];
+        uint64_t m[16];
+        uint32_t flag = 0;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const f32x4 a = areg[tt];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+#ifndef MS_ABL_NOFILTER
+            if (tt >= 2 && tt < 6) filter_group(prev, t - 1, tt - 2, false, sc, m);
+#else
+            if (tt == 2) { for (int i = 0; i < 16; ++i) { m[i] = 0; sc[i] = 0.0f; asm volatile("" :: "v"(prev[i])); } }
+#endif
+#ifndef MS_ABL_NOFLAG
+            if (tt == 4) {      // flag of tile t+1: read issued here, looked at three groups later (asm: hipcc would sink the read to its use)
+                const uint32_t fa = (uint32_t)(uintptr_t)(full + (t + 1) % LDR_R);     // LDS byte address
+                asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(fa) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
+#ifndef MS_ABL_NOFLAG
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) : : "memory");
+        flag = __builtin_amdgcn_readfirstlane(flag);
+#ifdef MS_STAMP
+        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) {
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+            wait_tile(t + 1);
+            stamp_wait += __builtin_amdgcn_s_memtime() - w0;
+            stamp_nwait += 1;
+        }
+#else
+        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) wait_tile(t + 1);   // normally long since published
+#endif
+#endif
+#pragma unroll
+        for (int tt = 8; tt < 16; ++tt) {
+            const f32x4 a = areg[tt];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+#ifndef MS_ABL_NOREFILL
+            const int f0 = 2 * (tt - 8);        // fragments of groups already consumed <- tile t+1
+            areg[f0] = src[(16 * h + f0) ^ (r & 15)];
+            areg[f0 + 1] = src[(16 * h + f0 + 1) ^ (r & 15)];
+#endif
+        }
+        out = acc;
+        uint64_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any |= m[i];
+        if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+    };
+
+#ifdef MS_STAMP
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (ntl > 0) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
+        wait_tile(0);
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) areg[tt] = ring[r * 32 + ((16 * h + tt) ^ (r & 15))];
+        // every tile, the partial last one included, goes through the pipeline; its rows past
+        // row_end are rejected by the filter of the last stage / the drain below
+        int t = 0;
+        for (; t + 1 < ntl; t += 2) {
+            stage(t, acc0, acc1);
+            stage(t + 1, acc1, acc0);
+        }
+        if (t < ntl) {
+            stage(t, acc0, acc1);
+            acc0 = acc1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) consumed[wave] = 0xFFFFFFFFu;
+        float sc[16];
+        uint64_t m[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) filter_group(acc0, ntl - 1, g, true, sc, m);
+        uint64_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any |= m[i];
+        if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
+    }
+#ifdef MS_STAMP
+    if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 32 + 32 <= 4 * 4 * 65536) {
+        unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 4;
+        o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        o[2] = (unsigned long long)ntl;
+        o[3] = (stamp_nwait << 40) | stamp_wait;
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        const int rank = h * KL + j;
+        if (rank < p.k) {
+            const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+            p.part_s[o] = st.ls[j];
+            p.part_i[o] = st.li[j];
+        }
+    }
+}
+
 // The full scan and the sample pass run the same body; two symbols so that profiles tell them apart.
-template <int KL, bool AUX, bool UB, bool SHARE>
-__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB, SHARE>(p); }
-template <int KL, bool AUX, bool SHARE>
-__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false, SHARE>(p); }
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB>(p); }
+template <int KL, bool AUX>
+__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false>(p); }
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -700,9 +1055,9 @@ int cu_count_cached() {
     return cus;
 }
 
-int share_tiles_setting() {
+int loader_wave_setting() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("MS_SHARE_TILES"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = getenv("MS_LOADER_WAVE"); v = e ? atoi(e) : 1; }
     return v;
 }
 
@@ -710,7 +1065,7 @@ int prepass_tiles_setting() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("MS_PREPASS_TILES");
-        v = e ? atoi(e) : 4;
+        v = e ? atoi(e) : 8;
         if (v < 0) v = 0;
     }
     return v;
@@ -780,18 +1135,25 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     return MS_OK;
 }
 
-template <int KL, bool AUX, bool UB, bool SHARE>
+template <int KL, bool AUX, bool UB>
 int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     if (!UB && sp.max_tiles > 0) {      // sample pass
-        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX, SHARE>),
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX, SHARE>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB, SHARE>),
+    if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches: loader-wave form
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, UB>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+        hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+        MS_LAUNCH_CHECK("ms_scan_loader_kernel");
+        return MS_OK;
+    }
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
-    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB, SHARE>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
     MS_LAUNCH_CHECK("ms_scan_kernel");
     return MS_OK;
 }
@@ -799,9 +1161,7 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
 template <int KL, bool UB>
 int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
-    const bool share = sp.qwb == 4 && share_tiles_setting();
-    if (aux) return share ? launch_scan_variant<KL, true, UB, true>(pl, sp, st) : launch_scan_variant<KL, true, UB, false>(pl, sp, st);
-    return share ? launch_scan_variant<KL, false, UB, true>(pl, sp, st) : launch_scan_variant<KL, false, UB, false>(pl, sp, st);
+    return aux ? launch_scan_variant<KL, true, UB>(pl, sp, st) : launch_scan_variant<KL, false, UB>(pl, sp, st);
 }
 
 // list width per pass: 5 entries per lane for k <= 10, else 32 (k <= 64)
@@ -823,6 +1183,22 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
 
 // ScanParams of the full pass from the workspace layout (queries prepared, inverse norms in the
 // workspace when the caller gave none)
+#ifdef MS_STAMP
+constexpr size_t MS_STAMP_WORDS = 4 * 4 * 65536;
+unsigned long long *ms_stamp_buffer() {
+    static unsigned long long *buf = nullptr;
+    if (buf == nullptr) {
+        if (hipMalloc(reinterpret_cast<void **>(&buf), MS_STAMP_WORDS * 8) != hipSuccess) return nullptr;
+        (void)hipMemset(buf, 0, MS_STAMP_WORDS * 8);
+    }
+    return buf;
+}
+extern "C" int ms_debug_stamps(unsigned long long *host, int words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(host, ms_stamp_buffer(), (size_t)words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, const float *inv_norm, const float *lengths,
                       const float *qlen, float mincov, char *ws, int mode, ScanParams *sp) {
     const float *inv = inv_norm;
@@ -830,12 +1206,19 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, co
     sp->db = db; sp->n = n; sp->qn = reinterpret_cast<const float *>(ws + pl.off_qn); sp->nq = nq; sp->nq_pad = pl.nq_pad;
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
-    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
+    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0; sp->first_tile = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
     sp->qwb = pl.qwb; sp->n_qgroups = pl.n_qgroups; sp->n_sgroups = pl.n_sgroups; sp->P = pl.P;
+#ifdef MS_STAMP
+    sp->stamps = ms_stamp_buffer();
+#endif
 }
+
+// The loader-wave form of the full pass does not rescan the sampled tiles: it starts from the
+// per-(stream, query) lists the sample pass left in part_s / part_i.
+int resume_tile(const ScanPlan &pl) { return (pl.prepass_tiles > 0 && pl.qwb == 4 && loader_wave_setting()) ? pl.prepass_tiles : 0; }
 
 // Sample pass: scan the first prepass_tiles tiles of every stream, merge, and leave the k-th
 // best score per query in the workspace (off_ub_s doubles as the buffer) as the lower bound
@@ -854,6 +1237,7 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     rc = launch_merge(pl, s0, nq, s0.k, 0, scratch_s, scratch_i, s0.k, 0, lb, lb_i, st);
     if (rc) return rc;
     sp->lb_s = lb;
+    sp->first_tile = resume_tile(pl);
     return MS_OK;
 }
 
@@ -946,7 +1330,10 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     ScanParams sp;
     // same parameters as ms_ip_topk_prepare left in the workspace (queries, inverse norms, lower bound)
     fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
-    if (pl.prepass_tiles > 0) sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
+    if (pl.prepass_tiles > 0) {
+        sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
+        sp.first_tile = resume_tile(pl);
+    }
     return launch_scan(pl, sp, (hipStream_t)stream);
 }
 

@@ -31,11 +31,11 @@ for n, nq, k in cases:
         ops.ip_topk_prepare(d, qq, k, ws, **kw); ops.ip_topk_scan(d, qq, k, ws, **kw); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    reps = 10; ts = 0.0; tm = 0.0
+    reps = int(os.environ.get('DIAG_REPS', '30')); tsl = []; tml = []
     for _ in range(reps):
         e[0].record(); ops.ip_topk_prepare(d, qq, k, ws, **kw); ops.ip_topk_scan(d, qq, k, ws, **kw); e[1].record(); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i); e[2].record()
-        torch.cuda.synchronize(); ts += e[0].elapsed_time(e[1]); tm += e[1].elapsed_time(e[2])
-    ts /= reps; tm /= reps
+        torch.cuda.synchronize(); tsl.append(e[0].elapsed_time(e[1])); tml.append(e[1].elapsed_time(e[2]))
+    ts = float(np.median(tsl)); tm = float(np.median(tml))
     fl = 2.0 * 128 * nq * n
     print(f"n={n} nq={nq} k={k}: scan {ts*1e3:.1f} us merge {tm*1e3:.1f} us | {fl/ts/1e9:.1f} TFLOP/s ({fl/ts/1e9/157.3*100:.1f}% mfma) "
           f"{n*512/ts/1e9*1e3/1e3:.2f} TB/s ({n*512/ts/1e6/8000*100:.1f}% hbm) | {nq/((ts+tm)/1e3):.0f} q/s")

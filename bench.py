@@ -14,10 +14,12 @@ The database and the queries are resident in HBM before the timed region starts.
 `--rows 365000000 --nq 4096` runs the TED-scale shape (C4).
 
 One JSON line is printed by rank 0 (contract in the task statement), with
-  roofline     for the dominant kernel (ms_scan_kernel): algorithmic flops (2*128*nq*rows per
-               launch) over the HIP-event duration of the scan stage, against the fp32 MFMA
-               peak (157.3 TFLOP/s) when nq >= 39, else algorithmic bytes (512 B per row)
-               against the 8 TB/s HBM peak; both fractions are always included;
+  roofline     for the dominant kernel (ms_scan_loader_kernel; ms_scan_kernel for < 3 query tiles):
+               algorithmic flops (2*128*nq per row) x the rows THAT launch scans (the shard minus
+               the tiles the sample pass already scored, ms_ip_topk_scan_rows) over the HIP-event
+               duration of the scan stage, against the fp32 MFMA peak (157.3 TFLOP/s) when
+               nq >= 39, else algorithmic bytes (512 B per row) against the 8 TB/s HBM peak;
+               both fractions are always included;
   cpu_baseline the CPU oracle (oracle/oracle.c, a restatement of the reference's faiss path)
                timed on this host's cores on a bounded sample of the same workload.
 """
@@ -96,7 +98,7 @@ def main():
         ops.ip_topk_prepare(db, q, k, ws)                               # queries + sample pass (lower bound)
         if events is not None:
             events[0].record()
-        ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE ms_scan_kernel launch
+        ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE scan launch
         if events is not None:
             events[1].record()
         ops.ip_topk_finish(n_local, nq, k, ws, out_s, out_i, row_offset=lo)
@@ -142,8 +144,9 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
-        flops = 2.0 * 128 * nq * n_local
-        bytes_ = 512.0 * n_local
+        scan_rows = int(_lib.load().ms_ip_topk_scan_rows(n_local, nq, k))      # rows the timed launch scans
+        flops = 2.0 * 128 * nq * scan_rows
+        bytes_ = 512.0 * scan_rows
         t_scan = scan_ms * 1e-3
         mfma_frac = flops / t_scan / MFMA_F32_PEAK
         hbm_frac = bytes_ / t_scan / HBM_PEAK
@@ -153,15 +156,16 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": bytes_ / t_scan / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": hbm_frac, "traffic": None}
-        roof.update({"kernel": "ms_scan_kernel", "kernel_ms": scan_ms, "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
+        roof.update({"kernel": "ms_scan_loader_kernel" if nq > 64 else "ms_scan_kernel", "kernel_ms": scan_ms,
+                     "mfma_frac": mfma_frac, "hbm_frac": hbm_frac, "rows_per_launch": scan_rows,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
         # HBM traffic of one launch of that kernel from the committed PMC passes of this same command
         # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction applied)
-        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v4.json")
+        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v5.json")
         if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10) and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_c2_pmc_v4.json"
+            roof["traffic_source"] = "profiles/r01_c2_pmc_v5.json"
         line = {
             "metric": "queries/sec (exact 128-d cosine top-k, recall@k vs brute force = %.3f)" % recall,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -160,22 +160,27 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
     const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
     const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
     const bool spill = (h == 1) && (cand > pl_s);
-    float in_s = spill ? pl_s : cand;
-    uint32_t in_i = spill ? pl_i : crow;
-    if (h == 0) { in_s = cand; in_i = crow; }
-    bool taken = false;
+    // Sorted insert without a serial compare-exchange chain: with ge[e] = (old ls[e] >= x),
+    //     new ls[e] = ge[e] ? ls[e] : (ge[e-1] ? x : ls[e-1])        (ge[-1] = true)
+    // so every entry needs one compare and two selects per array, all on OLD values (updated in
+    // place from the last entry down).  New rows lose ties (>=: ascending row order).  A spilled
+    // entry is not below anything in lane q+32's half (the pair's list is sorted), so it goes to
+    // position 0: its compare value is NaN (ge false everywhere).  No candidate: x = -inf, ge true.
+    const float x_cmp = spill ? __builtin_nanf("") : cand;
+    const float ins_s = spill ? pl_s : cand;
+    const uint32_t ins_i = spill ? pl_i : crow;
+    bool ge_hi = st.ls[KL - 1] >= x_cmp;
 #pragma unroll
-    for (int e = 0; e < KL; ++e) {
-        // new rows lose ties (ascending row order); a spilled entry wins them
-        const bool take = taken || (in_s > st.ls[e]) || (spill && in_s == st.ls[e]);
-        const float ts = st.ls[e];
-        const uint32_t ti = st.li[e];
-        st.ls[e] = take ? in_s : ts;
-        st.li[e] = take ? in_i : ti;
-        in_s = take ? ts : in_s;
-        in_i = take ? ti : in_i;
-        taken = take;
+    for (int e = KL - 1; e >= 1; --e) {
+        const bool ge_lo = st.ls[e - 1] >= x_cmp;
+        const float ns = ge_lo ? ins_s : st.ls[e - 1];
+        const uint32_t ni = ge_lo ? ins_i : st.li[e - 1];
+        st.ls[e] = ge_hi ? st.ls[e] : ns;
+        st.li[e] = ge_hi ? st.li[e] : ni;
+        ge_hi = ge_lo;
     }
+    st.ls[0] = ge_hi ? st.ls[0] : ins_s;
+    st.li[0] = ge_hi ? st.li[0] : ins_i;
     const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
     st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
 }
@@ -1300,6 +1305,20 @@ int ms_row_inv_norms(const float *x, int64_t n, int d, float eps, float *inv_nor
 size_t ms_ip_topk_workspace_bytes(int64_t n, int nq, int k) {
     if (n < 0 || nq < 1 || k < 1) return 0;
     return make_plan(n, nq, k, cu_count_cached()).total;
+}
+
+int64_t ms_ip_topk_scan_rows(int64_t n, int nq, int k) {
+    if (n < 0 || nq < 1 || k < 1 || k > 64) return -1;
+    const ScanPlan pl = make_plan(n, nq, k, cu_count_cached());
+    const int64_t skip = (int64_t)resume_tile(pl) * 32;
+    if (skip == 0) return n;
+    int64_t rows = 0;
+    for (int s = 0; s < pl.n_streams; ++s) {
+        const int64_t b = (int64_t)s * pl.rows_per_stream;
+        const int64_t e = b + pl.rows_per_stream < n ? b + pl.rows_per_stream : n;
+        if (e - b > skip) rows += e - b - skip;
+    }
+    return rows;
 }
 
 int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,

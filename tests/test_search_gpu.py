@@ -230,6 +230,46 @@ def test_sample_prepass_is_exact_on_adversarial_order(torch_gpu):
     assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("n,nq,k", [
+    (131_073, 96, 10), (131_105, 96, 10), (200_000, 130, 5), (262_113, 97, 1), (400_000, 256, 10), (300_000, 100, 64),
+    (1_000_003, 256, 10),
+])
+def test_loader_wave_scan_resumes_from_sample_lists(n, nq, k, torch_gpu):
+    """Batches of >= 3 query tiles run the loader-wave kernel, which starts from the lists the
+    sample pass built over the first tiles of every row stream instead of rescanning them.
+    Sizes around stream boundaries (last stream shorter than the sample, partial last tile)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    db = _norm_db(n, seed=81 + n % 5)
+    q = _norm_db(nq, seed=82)
+    db[n - 1] = db[3]; db[n // 2] = db[3]; db[40] = db[n - 2]          # duplicates: sampled vs unsampled rows
+    s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), k, row_offset=7)
+    s_ref, i_ref = orc.ip_topk(db, q, k, row_offset=7, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+def test_loader_wave_all_equal_scores_and_cosine_mask(torch_gpu):
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    n, nq, k = 300_000, 96, 7
+    db = np.tile(_norm_db(1, seed=5), (n, 1))          # every score ties: the lowest rows win, through the resume too
+    s, i = ops.ip_topk(_dev(torch, db), _dev(torch, _norm_db(nq, seed=6)), k)
+    assert (i.cpu().numpy() == np.arange(k)[None, :]).all()
+    # cosine mode (row scale + length mask staged by the loader wave) against the oracle
+    n, nq, k = 250_000, 100, 10
+    raw, lengths = syn.raw_database(n, seed=90)
+    rq, qlen = syn.raw_queries(nq, seed=91)
+    d = _dev(torch, raw)
+    s, i = ops.ip_topk(d, _dev(torch, rq), k, mode=ops.MODE_COSINE_RAW, inv_norm=ops.row_inv_norms(d),
+                       lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
+    s_ref, i_ref = orc.cosine_topk(raw, rq, k, lengths, qlen, 0.7)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+
+
 def test_staged_api_equals_one_shot_and_all_equal_scores(torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops

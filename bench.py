@@ -15,11 +15,10 @@ The database and the queries are resident in HBM before the timed region starts.
 
 One JSON line is printed by rank 0 (contract in the task statement), with
   roofline     for the dominant kernel (ms_scan_loader_kernel; ms_scan_kernel for < 3 query tiles):
-               algorithmic flops (2*128*nq per row) x the rows THAT launch scans (the shard minus
-               the tiles the sample pass already scored, ms_ip_topk_scan_rows) over the HIP-event
-               duration of the scan stage, against the fp32 MFMA peak (157.3 TFLOP/s) when
-               nq >= 39, else algorithmic bytes (512 B per row) against the 8 TB/s HBM peak;
-               both fractions are always included;
+               algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the
+               scan stage, against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else
+               algorithmic bytes (512 B per row) against the 8 TB/s HBM peak; both fractions
+               are always included;
   cpu_baseline the CPU oracle (oracle/oracle.c, a restatement of the reference's faiss path)
                timed on this host's cores on a bounded sample of the same workload.
 """
@@ -144,7 +143,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = nq * args.steps / elapsed
-        scan_rows = int(_lib.load().ms_ip_topk_scan_rows(n_local, nq, k))      # rows the timed launch scans
+        scan_rows = n_local                                                     # the timed launch scans every row of the shard
         flops = 2.0 * 128 * nq * scan_rows
         bytes_ = 512.0 * scan_rows
         t_scan = scan_ms * 1e-3

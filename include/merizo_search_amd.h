@@ -75,17 +75,11 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
 /* The three stages of ms_ip_topk for k <= 64, exposed so that a profiler / bench can time the
  * scan kernel alone.  Call them in order with identical arguments:
  *   ms_ip_topk_prepare  queries -> padded (cosine: normalised) copy, inverse row norms if absent,
- *                       and the sample pass (first tiles of every row stream -> a lower bound on
- *                       each query's k-th best score);
+ *                       and the sample pass (best rows of the first tiles of every row stream -> a
+ *                       lower bound on each query's k-th best score);
  *   ms_ip_topk_scan     ONE launch of the fused score + top-k scan over all remaining rows
  *                       (ms_scan_loader_kernel for batches of >= 3 query tiles, else ms_scan_kernel);
- *                       exactly one call per ms_ip_topk_prepare: it consumes the sample pass's lists;
  *   ms_ip_topk_finish   merge of the per-stream lists into the outputs. */
-/* Rows of an n-row shard that the ms_ip_topk_scan launch itself processes (k <= 64): n, minus the
- * first tiles of every row stream when the scan resumes from the lists the sample pass built
- * over them (those rows are scored once, by ms_ip_topk_prepare).  For throughput / roofline
- * accounting of that launch; -1 on bad arguments. */
-int64_t ms_ip_topk_scan_rows(int64_t n, int nq, int k);
 int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
                        const float *lengths, const float *qlen, float mincov, void *workspace,
                        size_t workspace_bytes, ms_stream_t stream);

@@ -40,7 +40,6 @@ SIGNATURES = {
     "ms_l2_normalize_rows": (_int, [_vp, _i64, _int, _f, _vp]),
     "ms_row_inv_norms": (_int, [_vp, _i64, _int, _f, _vp, _vp]),
     "ms_ip_topk_workspace_bytes": (_sz, [_i64, _int, _int]),
-    "ms_ip_topk_scan_rows": (_i64, [_i64, _int, _int]),
     "ms_ip_topk": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),
     "ms_ip_topk_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),

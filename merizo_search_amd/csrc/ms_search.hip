@@ -100,8 +100,6 @@ struct ScanParams {
     const uint32_t *ub_i;
     const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
     int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
-    int first_tile;         // > 0 (loader-wave form only): the first tiles of every stream were scanned by the sample
-                            // pass; start from its lists (still in part_s / part_i) at this tile
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
     int rows_per_stream;    // multiple of 32
@@ -222,7 +220,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
     }
 }
 
-template <int KL, bool AUX, bool UB>
+template <int KL, bool AUX, bool UB, bool MAXONLY>
 __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -258,6 +256,10 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     st.tau = -INFINITY;
 #endif
 
+    // MAXONLY (sample pass): no lists, only this lane's best row so far (its half of every tile)
+    float smax = -INFINITY;
+    uint32_t srow = MS_IDX_NONE;
+
     if (active) {
         const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
         int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
@@ -291,7 +293,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         float ubs = INFINITY;
         uint32_t ubi = 0;
         if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
-
         // LDS-DMA of one tile into slot (t & 1).  Instruction `it` fills float4 slots 64 it .. 64 it + 63,
         // i.e. rows 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
         // Per-lane byte offset inside the tile for instruction it:
@@ -356,6 +357,14 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                     s = (sub_row0 >= row_begin) ? sv : -INFINITY;   // "tile -1" of the pipeline has no aux data
                 }
                 sc[4 * g + j] = s;
+                if (MAXONLY) {      // strict >: the lowest row wins ties; -inf / NaN scores never enter
+                    bool ok = s > smax;
+                    if (check_rows) ok = ok && (rbase + j < row_end);
+                    smax = ok ? s : smax;
+                    srow = ok ? (uint32_t)(rbase + j) : srow;
+                    m[4 * g + j] = 0;
+                    continue;
+                }
                 bool pass = s > st.tau;
                 if (check_rows) pass = pass && (rbase + j < row_end);
                 if (UB) {
@@ -476,6 +485,19 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (any != 0) ms_tile_insert<KL>(st, sc, m, tail_row0, r, h);
         }
     }
+    if (MAXONLY && active) {
+        // the stream's list = the two half-tile maxima of the lane pair (distinct rows), best first,
+        // in lane q; lane q+32 stays empty
+        const float ps2 = ms_xor32_f(smax, h);
+        const uint32_t pr2 = ms_xor32_u(srow, h);
+        if (h == 0) {
+            const bool mine_first = ms_better(smax, srow, ps2, pr2);
+            st.ls[0] = mine_first ? smax : ps2; st.li[0] = mine_first ? srow : pr2;
+            st.ls[1] = mine_first ? ps2 : smax; st.li[1] = mine_first ? pr2 : srow;
+            if (st.li[0] == MS_IDX_NONE) st.ls[0] = -INFINITY;
+            if (st.li[1] == MS_IDX_NONE) st.ls[1] = -INFINITY;
+        }
+    }
     const int KLc = KL;
     float (&ls)[KL] = st.ls;
     uint32_t (&li)[KL] = st.li;
@@ -592,11 +614,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     const int stream = super * 8 + (within & 7);      // qwb == 4: one stream per workgroup
     const int qg = within >> 3;
     if (stream >= p.n_streams) return;
-    const int64_t stream_begin = (int64_t)stream * p.rows_per_stream;
-    const int64_t row_end = (stream_begin + p.rows_per_stream < p.n) ? stream_begin + p.rows_per_stream : p.n;
-    // resume: rows before first_tile are already in the lists the sample pass left behind
-    int64_t row_begin = stream_begin + (int64_t)p.first_tile * 32;
-    if (row_begin > row_end) row_begin = row_end;
+    const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
+    const int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
     const int nfull = (int)((row_end - row_begin) >> 5);
     const int rem = (int)((row_end - row_begin) & 31);
     const int ntl = nfull + (rem > 0 ? 1 : 0);        // tiles the loader delivers (the last one may be partial)
@@ -714,22 +733,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
 #ifndef MS_DEBUG_NO_INSERT
         st.tau = st.floor;
-#endif
-    }
-    if (p.first_tile > 0) {
-        // the lists of this (stream, query) as the sample pass wrote them: ranks h*KL .. h*KL+KL-1 of the lane pair
-#pragma unroll
-        for (int j = 0; j < KL; ++j) {
-            const int rank = h * KL + j;
-            if (rank < p.k) {
-                const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
-                st.ls[j] = p.part_s[o];
-                st.li[j] = p.part_i[o];
-            }
-        }
-#ifndef MS_DEBUG_NO_INSERT
-        const float worst = ms_xor32_f(st.ls[KL - 1], h);           // lane q+32's last entry = the pair's worst
-        st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
 #endif
     }
     if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
@@ -906,9 +909,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 
 // The full scan and the sample pass run the same body; two symbols so that profiles tell them apart.
 template <int KL, bool AUX, bool UB>
-__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB>(p); }
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB, false>(p); }
 template <int KL, bool AUX>
-__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false>(p); }
+__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false, true>(p); }
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -1008,6 +1011,89 @@ __global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part
     }
 }
 
+// Head-advance form of the same merge for small k * P (the usual case: k = 10, P <= 128 lists):
+// one wave per query stages the [k][P] block in LDS, then runs k rounds of "best list head
+// wins and its list advances" -- a wave-level arg-max per round, no block barrier, no pool.
+template <int PER>      // lists per lane: P <= 64 * PER
+__global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
+                                                          int64_t row_offset, float *out_s, int64_t *out_i,
+                                                          int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint2 *ent = reinterpret_cast<uint2 *>(smem);               // [k][P]
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float *ps = part_s + (size_t)q * k * P;
+    const uint32_t *pi = part_i + (size_t)q * k * P;
+#pragma unroll 8
+    for (int e = lane; e < k * P; e += 64) ent[e] = make_uint2(__float_as_uint(ps[e]), pi[e]);
+    __syncthreads();
+    float hs[PER];
+    uint32_t hi[PER];
+    int dep[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pp = lane + 64 * u;
+        hs[u] = -INFINITY; hi[u] = MS_IDX_NONE; dep[u] = 0;
+        if (pp < P) { const uint2 e = ent[pp]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
+    }
+    const size_t o0 = (size_t)q * out_stride + out_col0;
+    for (int round = 0; round < k; ++round) {
+        float bs = hs[0];
+        uint32_t bi = hi[0];
+        int bu = 0;
+#pragma unroll
+        for (int u = 1; u < PER; ++u)
+            if (ms_better(hs[u], hi[u], bs, bi)) { bs = hs[u]; bi = hi[u]; bu = u; }
+        // wave arg-max: 4 DPP steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror, row
+        // mirror: max is idempotent, so mirrors all-reduce as well as a butterfly), then the 4 row
+        // results through SGPRs -- no LDS-crossbar shuffles in the round
+        float ws = bs;
+        uint32_t wi = bi;
+#define MS_DPP_STEP(CTRL)                                                                                         \
+        {                                                                                                         \
+            const float os = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ws), CTRL, 0xF, 0xF, false)); \
+            const uint32_t oi = __builtin_amdgcn_update_dpp(0u, wi, CTRL, 0xF, 0xF, false);                       \
+            if (ms_better(os, oi, ws, wi)) { ws = os; wi = oi; }                                                  \
+        }
+        MS_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
+        MS_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
+        MS_DPP_STEP(0x141)     // row_half_mirror
+        MS_DPP_STEP(0x140)     // row_mirror
+#undef MS_DPP_STEP
+        {
+            float rs = ms_readlane_f(ws, 0);
+            uint32_t ri = ms_readlane_u(wi, 0);
+#pragma unroll
+            for (int row = 1; row < 4; ++row) {
+                const float os = ms_readlane_f(ws, 16 * row);
+                const uint32_t oi = ms_readlane_u(wi, 16 * row);
+                if (ms_better(os, oi, rs, ri)) { rs = os; ri = oi; }
+            }
+            ws = rs; wi = ri;
+        }
+        if (wi == MS_IDX_NONE) {                                // every list is exhausted: pad the tail
+            if (lane == 0) {
+                for (int r2 = round; r2 < k; ++r2) { out_s[o0 + r2] = -INFINITY; out_i[o0 + r2] = -1; }
+                if (ub_s != nullptr) { ub_s[q] = -INFINITY; ub_i[q] = MS_IDX_NONE; }
+            }
+            break;
+        }
+        if (lane == 0) {
+            out_s[o0 + round] = ws;
+            out_i[o0 + round] = row_offset + (int64_t)wi;
+            if (round == k - 1 && ub_s != nullptr) { ub_s[q] = ws; ub_i[q] = wi; }
+        }
+        if (bi == wi) {                                         // rows are unique across lists: exactly one lane
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                if (u != bu) continue;
+                const int d = ++dep[u];
+                hs[u] = -INFINITY; hi[u] = MS_IDX_NONE;
+                if (d < k) { const uint2 e = ent[(size_t)d * P + lane + 64 * u]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ public k-way merge -
 // One thread per query: classic k-way merge of S lists that are each sorted best-first.
 __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores, const int64_t *idx, int S, int nq,
@@ -1063,6 +1149,12 @@ int cu_count_cached() {
 int loader_wave_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_LOADER_WAVE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+int head_merge_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_HEAD_MERGE"); v = e ? atoi(e) : 1; }
     return v;
 }
 
@@ -1179,6 +1271,21 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
+    const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
+    if (head_lds <= 48 * 1024 && head_merge_setting()) {        // small k * P: one wave per query, k arg-max rounds
+        const int per = (pl.P + 63) / 64;
+#define MS_HEAD_MERGE(PER)                                                                                             \
+    hipLaunchKernelGGL(ms_head_merge_kernel<PER>, dim3(nq), dim3(64), head_lds, st, sp.part_s, sp.part_i, pl.P, kp,    \
+                       row_offset, out_s, out_i, out_stride, col0, ub_s, ub_i)
+        if (per <= 1) MS_HEAD_MERGE(1);
+        else if (per <= 2) MS_HEAD_MERGE(2);
+        else if (per <= 4) MS_HEAD_MERGE(4);
+        else if (per <= 8) MS_HEAD_MERGE(8);
+        else MS_HEAD_MERGE(16);
+#undef MS_HEAD_MERGE
+        MS_LAUNCH_CHECK("ms_head_merge_kernel");
+        return MS_OK;
+    }
     const size_t lds = ((size_t)kp * kp + kp) * sizeof(uint2);
     hipLaunchKernelGGL(ms_partial_merge_kernel, dim3(nq), dim3(256), lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset,
                        out_s, out_i, out_stride, col0, ub_s, ub_i);
@@ -1211,7 +1318,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, co
     sp->db = db; sp->n = n; sp->qn = reinterpret_cast<const float *>(ws + pl.off_qn); sp->nq = nq; sp->nq_pad = pl.nq_pad;
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
-    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0; sp->first_tile = 0;
+    sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -1220,10 +1327,6 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, co
     sp->stamps = ms_stamp_buffer();
 #endif
 }
-
-// The loader-wave form of the full pass does not rescan the sampled tiles: it starts from the
-// per-(stream, query) lists the sample pass left in part_s / part_i.
-int resume_tile(const ScanPlan &pl) { return (pl.prepass_tiles > 0 && pl.qwb == 4 && loader_wave_setting()) ? pl.prepass_tiles : 0; }
 
 // Sample pass: scan the first prepass_tiles tiles of every stream, merge, and leave the k-th
 // best score per query in the workspace (off_ub_s doubles as the buffer) as the lower bound
@@ -1242,7 +1345,6 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     rc = launch_merge(pl, s0, nq, s0.k, 0, scratch_s, scratch_i, s0.k, 0, lb, lb_i, st);
     if (rc) return rc;
     sp->lb_s = lb;
-    sp->first_tile = resume_tile(pl);
     return MS_OK;
 }
 
@@ -1307,20 +1409,6 @@ size_t ms_ip_topk_workspace_bytes(int64_t n, int nq, int k) {
     return make_plan(n, nq, k, cu_count_cached()).total;
 }
 
-int64_t ms_ip_topk_scan_rows(int64_t n, int nq, int k) {
-    if (n < 0 || nq < 1 || k < 1 || k > 64) return -1;
-    const ScanPlan pl = make_plan(n, nq, k, cu_count_cached());
-    const int64_t skip = (int64_t)resume_tile(pl) * 32;
-    if (skip == 0) return n;
-    int64_t rows = 0;
-    for (int s = 0; s < pl.n_streams; ++s) {
-        const int64_t b = (int64_t)s * pl.rows_per_stream;
-        const int64_t e = b + pl.rows_per_stream < n ? b + pl.rows_per_stream : n;
-        if (e - b > skip) rows += e - b - skip;
-    }
-    return rows;
-}
-
 int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
                        const float *lengths, const float *qlen, float mincov, void *workspace, size_t workspace_bytes,
                        ms_stream_t stream) {
@@ -1349,10 +1437,7 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     ScanParams sp;
     // same parameters as ms_ip_topk_prepare left in the workspace (queries, inverse norms, lower bound)
     fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
-    if (pl.prepass_tiles > 0) {
-        sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
-        sp.first_tile = resume_tile(pl);
-    }
+    if (pl.prepass_tiles > 0) sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
     return launch_scan(pl, sp, (hipStream_t)stream);
 }
 

@@ -234,10 +234,10 @@ def test_sample_prepass_is_exact_on_adversarial_order(torch_gpu):
     (131_073, 96, 10), (131_105, 96, 10), (200_000, 130, 5), (262_113, 97, 1), (400_000, 256, 10), (300_000, 100, 64),
     (1_000_003, 256, 10),
 ])
-def test_loader_wave_scan_resumes_from_sample_lists(n, nq, k, torch_gpu):
-    """Batches of >= 3 query tiles run the loader-wave kernel, which starts from the lists the
-    sample pass built over the first tiles of every row stream instead of rescanning them.
-    Sizes around stream boundaries (last stream shorter than the sample, partial last tile)."""
+def test_loader_wave_scan_with_sample_bound(n, nq, k, torch_gpu):
+    """Batches of >= 3 query tiles run the loader-wave kernel, thresholded from its first tile by
+    the sample pass's lower bound.  Sizes around stream boundaries (last stream shorter than the
+    sample, partial last tile), duplicates between sampled and unsampled rows."""
     torch = torch_gpu
     from merizo_search_amd import ops
     from oracle import oracle as orc
@@ -256,7 +256,7 @@ def test_loader_wave_all_equal_scores_and_cosine_mask(torch_gpu):
     from merizo_search_amd.foldclass import synthetic as syn
     from oracle import oracle as orc
     n, nq, k = 300_000, 96, 7
-    db = np.tile(_norm_db(1, seed=5), (n, 1))          # every score ties: the lowest rows win, through the resume too
+    db = np.tile(_norm_db(1, seed=5), (n, 1))          # every score ties: the lowest rows win
     s, i = ops.ip_topk(_dev(torch, db), _dev(torch, _norm_db(nq, seed=6)), k)
     assert (i.cpu().numpy() == np.arange(k)[None, :]).all()
     # cosine mode (row scale + length mask staged by the loader wave) against the oracle

@@ -40,8 +40,8 @@ HBM_PEAK = 8.0e12            # same guide, "HBM3E peak BW" (spec)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--rows", type=int, default=1_000_000, help="total database rows (sharded over the ranks)")
     ap.add_argument("--nq", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)

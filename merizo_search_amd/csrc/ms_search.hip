@@ -134,8 +134,10 @@ __device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_f
 // The running top-k of query q lives in the REGISTERS of its two lanes (q, q+32): lane q holds
 // ranks 0..KL-1, lane q+32 ranks KL..2KL-1, sorted.  An insertion step handles one database
 // row for all 32 queries at once (SIMD over queries): the candidate goes to lane q, lane q's
-// displaced last entry (one compare tells which) goes to lane q+32, both lanes run one
-// compare-exchange chain.  No atomics, no cross-wave traffic.
+// displaced last entry (one compare tells which) goes to lane q+32, both lanes update their
+// sorted half with one compare and four selects per entry.  No atomics, no cross-wave traffic.
+// (ms_scan_loader_kernel below is the form used for >= 3 query tiles; this one serves 1-2 query
+// tiles -- the HBM-bound regime -- and, with MAXONLY, the sample pass.)
 template <int KL>
 struct ScanState {
     float ls[KL];
@@ -695,8 +697,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             LST(lst_vm)
         }
 #ifdef MS_STAMP
-        if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 32 + 32 <= 4 * 4 * 65536) {
-            unsigned long long *o = p.stamps + ((size_t)bid * 8 + 4) * 4;
+        if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+            unsigned long long *o = p.stamps + ((size_t)bid * 8 + 4) * 8;
             o[0] = lst_poll; o[1] = lst_issue; o[2] = lst_vm; o[3] = (unsigned long long)ntl;
         }
 #endif
@@ -783,10 +785,30 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             m[4 * g + j] = __ballot(pass);
         }
     };
+    // Inside the pipeline (full tiles, no upper bound) the filter is cheaper still: final scores of
+    // group g -> sc, and the lane's running maximum over the tile; ONE compare per tile decides
+    // whether any of the 32 x 32 scores can matter, the per-score ballots are taken only then.
+    auto scale_group = [&](const f32x16 &acc, int t, int g, float (&sc)[16], float &mx) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[4 * g + j];
+            if (AUX) {
+                const float *ax = auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h + j;
+                float sv = s * ax[0];
+                if (p.lengths != nullptr) {
+                    const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;
+                    sv = sv * mk;
+                }
+                s = (t >= 0) ? sv : -INFINITY;
+            }
+            sc[4 * g + j] = s;
+        }
+        mx = fmaxf(mx, fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
+    };
 
     f32x4 areg[16];
 #ifdef MS_STAMP
-    unsigned long long stamp_wait = 0, stamp_nwait = 0;
+    unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
 #endif
     auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
@@ -796,6 +818,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         const f32x4 *src = ring + ((t + 1) % LDR_R) * 1024 + r * 32;
         float sc[16];
         uint64_t m[16];
+        float mx = -INFINITY;
         uint32_t flag = 0;
         f32x16 acc;
 #pragma unroll
@@ -808,7 +831,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
 #ifndef MS_ABL_NOFILTER
-            if (tt >= 2 && tt < 6) filter_group(prev, t - 1, tt - 2, false, sc, m);
+            if (tt >= 2 && tt < 6) {
+                if (UB) filter_group(prev, t - 1, tt - 2, false, sc, m);
+                else scale_group(prev, t - 1, tt - 2, sc, mx);
+            }
 #else
             if (tt == 2) { for (int i = 0; i < 16; ++i) { m[i] = 0; sc[i] = 0.0f; asm volatile("" :: "v"(prev[i])); } }
 #endif
@@ -849,10 +875,23 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
         }
         out = acc;
-        uint64_t any = 0;
+        if (UB) {
+            uint64_t any = 0;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) any |= m[i];
-        if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+        } else if (__ballot(mx > st.tau) != 0) {
+#ifdef MS_STAMP
+            const unsigned long long i0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] = __ballot(sc[i] > st.tau);
+            ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+#ifdef MS_STAMP
+            stamp_ins += __builtin_amdgcn_s_memtime() - i0;
+            stamp_nins += 1;
+#endif
+        }
     };
 
 #ifdef MS_STAMP
@@ -888,12 +927,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
     }
 #ifdef MS_STAMP
-    if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 32 + 32 <= 4 * 4 * 65536) {
-        unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 4;
+    if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+        unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
         o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         o[2] = (unsigned long long)ntl;
         o[3] = (stamp_nwait << 40) | stamp_wait;
+        o[4] = stamp_ins; o[5] = stamp_nins;
     }
 #endif
 #pragma unroll
@@ -1162,7 +1202,7 @@ int prepass_tiles_setting() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("MS_PREPASS_TILES");
-        v = e ? atoi(e) : 8;
+        v = e ? atoi(e) : 32;
         if (v < 0) v = 0;
     }
     return v;
@@ -1201,7 +1241,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     pl.prepass_tiles = prepass_tiles_setting();
-    while (pl.prepass_tiles > 1 && tiles_per_stream < 16 * (int64_t)pl.prepass_tiles) pl.prepass_tiles /= 2;   // shorter streams: smaller sample
+    while (pl.prepass_tiles > 1 && tiles_per_stream < 30 * (int64_t)pl.prepass_tiles) pl.prepass_tiles /= 2;   // sample about 1/30 of a stream (measured optimum at 1M-16M rows x 256 queries)
     if (tiles_per_stream < 12 * (int64_t)pl.prepass_tiles || k > 64 || nq < 16) pl.prepass_tiles = 0;   // few queries: few insertions anyway
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);

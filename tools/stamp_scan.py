@@ -18,10 +18,10 @@ for n, nq, k in cases:
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ops.ip_topk_prepare(d, qq, k, ws); e0.record(); ops.ip_topk_scan(d, qq, k, ws); e1.record(); torch.cuda.synchronize()
-    words = 4 * 4 * 4096
+    words = 8 * 8 * 4096
     buf = np.zeros(words, dtype=np.uint64)
     assert lib.ms_debug_stamps(buf.ctypes.data, words) == 0
-    allw = buf.reshape(-1, 8, 4)
+    allw = buf.reshape(-1, 8, 8)
     ld = allw[:, 4, :]; ld = ld[ld[:, 3] > 0].astype(np.float64)
     if len(ld):
         print(f"   loader cycles/tile: poll {np.median(ld[:,0]/ld[:,3]):.0f} issue {np.median(ld[:,1]/ld[:,3]):.0f} vmcnt+publish {np.median(ld[:,2]/ld[:,3]):.0f}")
@@ -31,7 +31,9 @@ for n, nq, k in cases:
         cw = (ww[:, 3] & np.uint64((1 << 40) - 1)).astype(np.float64) / np.maximum(ww[:, 2].astype(np.float64), 1)
         nw = (ww[:, 3] >> np.uint64(40)).astype(np.float64)
         print(f"   wave {w}: wait cycles/tile median {np.median(cw):.0f}, misses median {np.median(nw):.0f}")
-    st = allw[:, :4, :].reshape(-1, 4); st = st[st[:, 2] > 0]
+    st = allw[:, :4, :].reshape(-1, 8); st = st[st[:, 2] > 0]
+    ni = st[:, 5].astype(np.float64); ci = st[:, 4].astype(np.float64)
+    print(f"   insert path: taken in {100*ni.sum()/st[:,2].astype(np.float64).sum():.1f}% of tiles, {ci.sum()/max(ni.sum(),1):.0f} cycles per visit")
     cyc, rt, nt = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64), st[:, 2].astype(np.float64)
     ghz = cyc / rt * 0.1
     nwait = (st[:, 3] >> np.uint64(40)).astype(np.float64); cwait = (st[:, 3] & np.uint64((1 << 40) - 1)).astype(np.float64)

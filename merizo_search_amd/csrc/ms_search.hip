@@ -190,7 +190,7 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
 template <int KL>
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
                                                int64_t sub_row0, int r, int h) {
-    if (KL <= 8) {
+    if (KL <= 10) {
         // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -290,8 +290,11 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
             }
         }
+        // cosine mode, branch-free: without a lengths array the mask test is +inf >= x * 0
         float my_qlen = 0.0f;
         if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+        const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;
+        const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
         float ubs = INFINITY;
         uint32_t ubi = 0;
         if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
@@ -343,19 +346,22 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         auto filter_group = [&](const f32x16 &acc, int64_t sub_row0, int g, bool check_rows, float (&sc)[16],
                                 uint64_t (&m)[16]) {
             const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+            f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (AUX) {
+                // the group's 4 row scales and 4 row lengths: two ds_read_b128.  Tile index from its first
+                // row; before the first tile (sub_row0 < row_begin, scores are -inf) any slot will do
+                const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
+                const f32x4 *ax = reinterpret_cast<const f32x4 *>(aux0 + tix * 64 + 8 * g + 4 * h);
+                inv4 = ax[0];
+                len4 = ax[8];
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float s = acc[4 * g + j];
                 if (AUX) {
-                    // tile index from its first row; before the first tile (sub_row0 < row_begin, scores
-                    // are -inf) any slot will do
-                    const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
-                    const float *ax = aux0 + tix * 64 + 8 * g + 4 * h + j;
-                    float sv = s * ax[0];                                                        // 1 / max(|row|, 1e-8)
-                    if (p.lengths != nullptr) {
-                        const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;           // dbsearch.py:76
-                        sv = sv * mk;                                                            // dbsearch.py:78
-                    }
+                    float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8)
+                    const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;           // dbsearch.py:76
+                    sv = sv * mk;                                                                // dbsearch.py:78
                     s = (sub_row0 >= row_begin) ? sv : -INFINITY;   // "tile -1" of the pipeline has no aux data
                 }
                 sc[4 * g + j] = s;
@@ -602,7 +608,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 compute, 4 loader
     const int r = lane & 31, h = lane >> 5;
-    f32x4 *ring = reinterpret_cast<f32x4 *>(smem);                                    // LDR_R x (32 x 32 float4)
+    // smem: LDR_R tile slots of 32 x 32 float4, then the aux ring, then the flag words
     float *auxring = reinterpret_cast<float *>(smem + LDR_R * 16384);                 // LDR_AUX x 64 floats
     // flag words, as explicit LDS (address space 3) pointers: a volatile access through a generic
     // pointer compiles to flat_load + s_waitcnt vmcnt(0), hundreds of cycles in the middle of a chain
@@ -749,6 +755,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     }
     float my_qlen = 0.0f;
     if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+    const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;      // no lengths: +inf >= x * 0
+    const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
     float ubs = INFINITY;
     uint32_t ubi = 0;
     if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
@@ -763,16 +771,19 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     auto filter_group = [&](const f32x16 &acc, int t, int g, bool check_rows, float (&sc)[16], uint64_t (&m)[16]) {
         const int64_t sub_row0 = row_begin + (int64_t)t * 32;
         const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+        f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (AUX) {          // the group's 4 row scales and 4 row lengths: two ds_read_b128
+            const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
+            inv4 = ax[0];
+            len4 = ax[8];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = acc[4 * g + j];
             if (AUX) {
-                const float *ax = auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h + j;
-                float sv = s * ax[0];                                                        // 1 / max(|row|, 1e-8)
-                if (p.lengths != nullptr) {
-                    const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;           // dbsearch.py:76
-                    sv = sv * mk;                                                            // dbsearch.py:78
-                }
+                float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8)
+                const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;           // dbsearch.py:76
+                sv = sv * mk;                                                                // dbsearch.py:78
                 s = (t >= 0) ? sv : -INFINITY;     // "tile -1" of the pipeline has no aux data
             }
             sc[4 * g + j] = s;
@@ -788,34 +799,41 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     // Inside the pipeline (full tiles, no upper bound) the filter is cheaper still: final scores of
     // group g -> sc, and the lane's running maximum over the tile; ONE compare per tile decides
     // whether any of the 32 x 32 scores can matter, the per-score ballots are taken only then.
-    auto scale_group = [&](const f32x16 &acc, int t, int g, float (&sc)[16], float &mx) {
+    auto scale_group = [&](f32x16 &acc, int t, int g, float &mx) {       // in place: acc <- final scores
+        f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (AUX) {
+            const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
+            inv4 = ax[0];
+            len4 = ax[8];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = acc[4 * g + j];
             if (AUX) {
-                const float *ax = auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h + j;
-                float sv = s * ax[0];
-                if (p.lengths != nullptr) {
-                    const float mk = (my_qlen >= ax[32] * p.mincov) ? 1.0f : 0.0f;
-                    sv = sv * mk;
-                }
+                float sv = s * inv4[j];
+                const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;
+                sv = sv * mk;
                 s = (t >= 0) ? sv : -INFINITY;
+                acc[4 * g + j] = s;
             }
-            sc[4 * g + j] = s;
         }
-        mx = fmaxf(mx, fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
     };
 
     f32x4 areg[16];
+    const uint32_t frag_a0 = (uint32_t)(r * 512 + 256 * h + 16 * (r & 15));    // fragment 0 of this lane inside a slot
 #ifdef MS_STAMP
     unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
 #endif
-    auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
+    auto stage = [&](int t, f32x16 &prev, f32x16 &out) {       // prev (raw scores of tile t-1) is scaled in place
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
 #ifndef MS_ABL_NOFLAG
         if (lane == 0) consumed[wave] = (uint32_t)(t + 1);
 #endif
-        const f32x4 *src = ring + ((t + 1) % LDR_R) * 1024 + r * 32;
+        // fragment f of this lane's row sits at float4 column (16 h + f) ^ (r & 15) of the slot:
+        // byte address = (slot + frag_a0) ^ (16 f) -- ONE address register and one v_xor per read
+        // instead of 16 precomputed lane offsets (the slot base has no bits below 2^14)
+        const uint32_t src_a0 = (uint32_t)(((t + 1) % LDR_R) * 16384) + frag_a0;
         float sc[16];
         uint64_t m[16];
         float mx = -INFINITY;
@@ -833,7 +851,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #ifndef MS_ABL_NOFILTER
             if (tt >= 2 && tt < 6) {
                 if (UB) filter_group(prev, t - 1, tt - 2, false, sc, m);
-                else scale_group(prev, t - 1, tt - 2, sc, mx);
+                else scale_group(prev, t - 1, tt - 2, mx);
             }
 #else
             if (tt == 2) { for (int i = 0; i < 16; ++i) { m[i] = 0; sc[i] = 0.0f; asm volatile("" :: "v"(prev[i])); } }
@@ -870,8 +888,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
 #ifndef MS_ABL_NOREFILL
             const int f0 = 2 * (tt - 8);        // fragments of groups already consumed <- tile t+1
-            areg[f0] = src[(16 * h + f0) ^ (r & 15)];
-            areg[f0 + 1] = src[(16 * h + f0 + 1) ^ (r & 15)];
+            areg[f0] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * f0)));
+            areg[f0 + 1] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * (f0 + 1))));
 #endif
         }
         out = acc;
@@ -885,7 +903,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll
-            for (int i = 0; i < 16; ++i) m[i] = __ballot(sc[i] > st.tau);
+            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
             ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
 #ifdef MS_STAMP
             stamp_ins += __builtin_amdgcn_s_memtime() - i0;
@@ -903,7 +921,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
         wait_tile(0);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) areg[tt] = ring[r * 32 + ((16 * h + tt) ^ (r & 15))];
+        for (int tt = 0; tt < 16; ++tt) areg[tt] = *reinterpret_cast<const f32x4 *>(smem + (frag_a0 ^ (uint32_t)(16 * tt)));
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
@@ -1167,7 +1185,7 @@ namespace {
 struct ScanPlan {
     int n_qtiles, qwb, n_qgroups, nq_pad;
     int k_pass;            // ranks per pass (<= 64)
-    int kl;                // list entries per lane: smallest of {5,16,32} with 2*kl >= k_pass
+    int kl;                // list entries per lane: smallest of {5,10,32} with 2*kl >= k_pass
     int rows_per_stream, n_streams, n_sgroups, P;
     int grid;
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
@@ -1209,8 +1227,8 @@ int prepass_tiles_setting() {
 }
 
 int pick_kl(int k_pass) {
-    const int opts[2] = {5, 32};
-    for (int i = 0; i < 2; ++i)
+    const int opts[3] = {5, 10, 32};
+    for (int i = 0; i < 3; ++i)
         if (2 * opts[i] >= k_pass) return opts[i];
     return 32;
 }
@@ -1281,12 +1299,14 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches: loader-wave form
-        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, UB>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
-        hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
-        MS_LAUNCH_CHECK("ms_scan_loader_kernel");
-        return MS_OK;
+    if constexpr (KL <= 10 && !UB) {    // loader-wave form: short lists only (its compute waves must fit 256 registers)
+        if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, UB>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            MS_LAUNCH_CHECK("ms_scan_loader_kernel");
+            return MS_OK;
+        }
     }
     MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
@@ -1305,6 +1325,7 @@ int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     if (sp.ub_s != nullptr) return launch_scan_kl<32, true>(pl, sp, st);
     if (pick_kl(sp.k) == 5) return launch_scan_kl<5, false>(pl, sp, st);
+    if (pick_kl(sp.k) == 10) return launch_scan_kl<10, false>(pl, sp, st);
     return launch_scan_kl<32, false>(pl, sp, st);
 }
 

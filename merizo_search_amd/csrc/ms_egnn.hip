@@ -225,6 +225,9 @@ struct EdgeParams {
     float *part;                  // [records][256]
     int nb;
     int total;
+#ifdef MS_STAMP
+    unsigned long long *stamps;   // diagnostic builds: per tile phase cycles
+#endif
 };
 
 __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
@@ -278,6 +281,13 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
 
+#ifdef MS_STAMP
+    unsigned long long tH = 0, tB1 = 0, tM = 0, tB2 = 0, tc = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tc;
+#define EST(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tc; tc = n_; }
+#else
+#define EST(acc)
+#endif
     for (int s = 0; s < NSTAGE; ++s) {
         // H = SiLU(Ap_i + Bp_j + w_c * d2), written straight into A-fragment order
 #pragma unroll
@@ -292,7 +302,9 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         }
 #pragma unroll
         for (int it = 0; it < 2 * STAGE_G; ++it) Wl[it * 256 + tid] = pw[it];
+        EST(tH)
         __syncthreads();
+        EST(tB1)
         if (s + 1 < NSTAGE) issue_loads(s + 1);
 #pragma unroll
         for (int g = 0; g < STAGE_G; ++g) {
@@ -306,8 +318,13 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
             }
         }
+        EST(tM)
         __syncthreads();
+        EST(tB2)
     }
+#ifdef MS_STAMP
+    const unsigned long long t_loop_end = tc;
+#endif
 
     // ---- epilogue.  acc[nt][r]: edge row (r&3) + 8(r>>2) + 4(lane>>5) of this wave's 32 rows,
     //      channel 32 nt + (lane & 31).
@@ -366,6 +383,12 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
             }
         }
     }
+#ifdef MS_STAMP
+    if (tid == 0 && p.stamps != nullptr && T < 32768) {
+        unsigned long long *o = p.stamps + 8 * (size_t)T;
+        o[0] = tH; o[1] = tB1; o[2] = tM; o[3] = tB2; o[4] = __builtin_amdgcn_s_memtime() - t_loop_end; o[5] = 1; o[6] = t_begin;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- node update ----------
@@ -379,6 +402,17 @@ struct NodeParams {
     float *h_out;                 // [total,128]
     int total;
 };
+
+#ifdef MS_STAMP
+unsigned long long *ms_egnn_stamp_buffer() {
+    static unsigned long long *buf = nullptr;
+    if (buf == nullptr) {
+        if (hipMalloc(reinterpret_cast<void **>(&buf), 8 * 32768 * 8) != hipSuccess) return nullptr;
+        (void)hipMemset(buf, 0, 8 * 32768 * 8);
+    }
+    return buf;
+}
+#endif
 
 __global__ __launch_bounds__(256) void ms_egnn_node_kernel(const NodeParams p) {
     __shared__ float xs[NODES_PB][NIN];      // [h, m_i]
@@ -493,6 +527,13 @@ size_t ms_egnn_workspace_bytes(int nb, int64_t total_residues, int64_t sum_sq) {
     return egnn_carve(nb, total_residues, sum_sq / 32 + 2 * total_residues + 1).total;
 }
 
+#ifdef MS_STAMP
+int ms_debug_egnn_stamps(unsigned long long *host, int words) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpy(host, ms_egnn_stamp_buffer(), (size_t)words * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float *coords, const int32_t *offsets,
                   const int32_t *offsets_host, int nb, float *out, void *workspace, size_t workspace_bytes,
                   ms_stream_t stream) {
@@ -540,6 +581,9 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
         EdgeParams ep;
         ep.prep = lp; ep.coords = coords; ep.offsets = offsets; ep.tile_pre = tile_pre; ep.rec_pre = rec_pre;
         ep.ApT4 = ap; ep.BpT4 = bp; ep.part = part; ep.nb = nb; ep.total = (int)total;
+#ifdef MS_STAMP
+        ep.stamps = ms_egnn_stamp_buffer();
+#endif
         hipLaunchKernelGGL(ms_egnn_edge_kernel, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
         MS_LAUNCH_CHECK("ms_egnn_edge_kernel");
         NodeParams np;

@@ -187,10 +187,13 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
 
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]; rows in ascending
 // order: row 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
+#ifndef MS_STATIC_INSERT_MAX_KL
+#define MS_STATIC_INSERT_MAX_KL 32
+#endif
 template <int KL>
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
                                                int64_t sub_row0, int r, int h) {
-    if (KL <= 10) {
+    if (KL <= MS_STATIC_INSERT_MAX_KL) {
         // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -1333,16 +1336,19 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
-    if (head_lds <= 48 * 1024 && head_merge_setting()) {        // small k * P: one wave per query, k arg-max rounds
+    if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
+    if (head_lds > 48 * 1024)                                                                                          \
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_head_merge_kernel<PER>),                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds));                  \
     hipLaunchKernelGGL(ms_head_merge_kernel<PER>, dim3(nq), dim3(64), head_lds, st, sp.part_s, sp.part_i, pl.P, kp,    \
                        row_offset, out_s, out_i, out_stride, col0, ub_s, ub_i)
-        if (per <= 1) MS_HEAD_MERGE(1);
-        else if (per <= 2) MS_HEAD_MERGE(2);
-        else if (per <= 4) MS_HEAD_MERGE(4);
-        else if (per <= 8) MS_HEAD_MERGE(8);
-        else MS_HEAD_MERGE(16);
+        if (per <= 1) { MS_HEAD_MERGE(1); }
+        else if (per <= 2) { MS_HEAD_MERGE(2); }
+        else if (per <= 4) { MS_HEAD_MERGE(4); }
+        else if (per <= 8) { MS_HEAD_MERGE(8); }
+        else { MS_HEAD_MERGE(16); }
 #undef MS_HEAD_MERGE
         MS_LAUNCH_CHECK("ms_head_merge_kernel");
         return MS_OK;

@@ -59,7 +59,7 @@ def main():
 
     from merizo_search_amd import _lib, ops
     from merizo_search_amd.foldclass import synthetic as syn
-    from merizo_search_amd.foldclass.sharded import ShardedIndex, allgather_results, shard_bounds
+    from merizo_search_amd.foldclass.sharded import PackedExchange, allgather_results, shard_bounds
 
     _lib.require_gpu()                                   # fails loudly without the HIP library / a GPU
     torch.cuda.set_device(local_rank)
@@ -89,8 +89,8 @@ def main():
         db[(flat_rows[mine] - lo).to(dev)] = planted.reshape(-1, 128)[mine].to(dev)
 
     ws = ops.TopKWorkspace(dev).get(n_local, nq, k)
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
-    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    ex = PackedExchange(nq, k, dev)        # this rank's results are written straight into its all-gather block
+    out_s, out_i = ex.out_s, ex.out_i
     shard_merge = ops.topk_merge
 
     def step(events=None):
@@ -102,8 +102,8 @@ def main():
             events[1].record()
         ops.ip_topk_finish(n_local, nq, k, ws, out_s, out_i, row_offset=lo)
         if world > 1:
-            gs, gi = allgather_results(out_s, out_i)
-            return shard_merge(gs, gi)
+            ex.exchange()                                                   # ONE RCCL all-gather of 12*nq*k bytes per rank
+            return ex.merge()                                               # merge of the S blocks in place
         return out_s, out_i
 
     def fence():

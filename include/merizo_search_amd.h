@@ -95,6 +95,12 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
 int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k, float *out_scores,
                   int64_t *out_idx, ms_stream_t stream);
 
+/* The same merge when list s of each array starts s * stride BYTES after list 0 -- e.g. straight out of
+ * the all-gather buffer, where every rank contributed one packed block [scores f32 nq*k | rows i64 nq*k]
+ * (no unpack copy between the collective and the merge). */
+int ms_topk_merge_strided(const float *scores, const int64_t *idx, int64_t score_stride_bytes, int64_t idx_stride_bytes,
+                          int S, int nq, int k, float *out_scores, int64_t *out_idx, ms_stream_t stream);
+
 /* ------------------------------------------------------------------ encoder --------- */
 
 /* Floats in the canonical weight blob of the whole encoder (2 EGNN layers, state_dict order:

@@ -45,6 +45,7 @@ SIGNATURES = {
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
+    "ms_topk_merge_strided": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_egnn_weight_floats": (_sz, []),
     "ms_egnn_prepared_bytes": (_sz, []),
     "ms_egnn_prepare_weights": (_int, [_vp, _vp, _vp]),

@@ -1157,8 +1157,10 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 
 // ------------------------------------------------------------------ public k-way merge -
 // One thread per query: classic k-way merge of S lists that are each sorted best-first.
-__global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores, const int64_t *idx, int S, int nq,
-                                                           int k, float *out_s, int64_t *out_i) {
+__global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores0, const int64_t *idx0, int64_t score_stride,
+                                                           int64_t idx_stride, int S, int nq, int k, float *out_s,
+                                                           int64_t *out_i) {
+    // list s lives at byte offset s * stride of each array (dense [S,nq,k] arrays: stride = nq*k elements)
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     constexpr int MAXS = 64;
@@ -1170,10 +1172,10 @@ __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores, 
         int64_t bi = 0;
         for (int s = 0; s < S; ++s) {
             if (head[s] >= k) continue;
-            const size_t o = ((size_t)s * nq + q) * k + head[s];
-            const int64_t ci = idx[o];
+            const size_t o = (size_t)q * k + head[s];
+            const int64_t ci = reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(idx0) + (size_t)s * idx_stride)[o];
             if (ci < 0) { head[s] = k; continue; }   // padding: list exhausted
-            const float cs = scores[o];
+            const float cs = reinterpret_cast<const float *>(reinterpret_cast<const char *>(scores0) + (size_t)s * score_stride)[o];
             if (best < 0 || cs > bs || (cs == bs && ci < bi)) { best = s; bs = cs; bi = ci; }
         }
         const size_t oo = (size_t)q * k + j;
@@ -1562,8 +1564,20 @@ int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k,
                   int64_t *out_idx, ms_stream_t stream) {
     if (S < 1 || S > 64 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
         MS_FAIL(MS_ERR_ARG, "ms_topk_merge: need 1 <= S <= 64, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
-    hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx, S, nq,
-                       k, out_scores, out_idx);
+    hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                       (int64_t)nq * k * 4, (int64_t)nq * k * 8, S, nq, k, out_scores, out_idx);
+    MS_LAUNCH_CHECK("ms_kway_merge_kernel");
+    return MS_OK;
+}
+
+int ms_topk_merge_strided(const float *scores, const int64_t *idx, int64_t score_stride_bytes, int64_t idx_stride_bytes,
+                          int S, int nq, int k, float *out_scores, int64_t *out_idx, ms_stream_t stream) {
+    if (S < 1 || S > 64 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
+        MS_FAIL(MS_ERR_ARG, "ms_topk_merge_strided: need 1 <= S <= 64, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
+    if (score_stride_bytes % 4 != 0 || idx_stride_bytes % 8 != 0 || ((uintptr_t)idx & 7) != 0)
+        MS_FAIL(MS_ERR_ARG, "ms_topk_merge_strided: strides / index pointer must keep float32 and int64 alignment");
+    hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                       score_stride_bytes, idx_stride_bytes, S, nq, k, out_scores, out_idx);
     MS_LAUNCH_CHECK("ms_kway_merge_kernel");
     return MS_OK;
 }

@@ -62,6 +62,63 @@ def allgather_results(scores, idx, group=None):
     return unpack_results(out, world, nq, k)
 
 
+class PackedExchange:
+    """Preallocated buffers for the per-batch exchange of a row-sharded search (serving loop).
+
+    ``out_s`` / ``out_i`` are views into this rank's packed block -- the local top-k is written
+    straight into it (ops.ip_topk_finish / ops.ip_topk outputs) -- ``exchange()`` is ONE
+    all-gather of that block, and ``merge()`` reads the S blocks in place
+    (ms_topk_merge_strided).  Per batch: no allocation, no pack / unpack copies.
+    """
+
+    def __init__(self, nq: int, k: int, device, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self.nq, self.k, self.group = nq, k, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.idx_offset = (4 * nq * k + 7) // 8 * 8                 # int64 rows start 8-byte aligned
+        self.block_bytes = self.idx_offset + 8 * nq * k
+        self.mine = torch.zeros(self.block_bytes, dtype=torch.uint8, device=device)
+        self.out_s = self.mine[: 4 * nq * k].view(torch.float32).reshape(nq, k)
+        self.out_i = self.mine[self.idx_offset:].view(torch.int64).reshape(nq, k)
+        self.gathered = torch.empty((self.world, self.block_bytes), dtype=torch.uint8, device=device)
+        self.merged_s = torch.empty((nq, k), dtype=torch.float32, device=device)
+        self.merged_i = torch.empty((nq, k), dtype=torch.int64, device=device)
+
+    def exchange(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.world == 1:
+            self.gathered[0].copy_(self.mine)
+        elif dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.gathered, self.mine, group=self.group)      # one RCCL all-gather over xGMI
+        else:
+            parts = [torch.empty_like(self.mine) for _ in range(self.world)]
+            dist.all_gather(parts, self.mine, group=self.group)
+            self.gathered.copy_(torch.stack(parts))
+        return self.gathered
+
+    def blocks(self):
+        """Views ([S,nq,k] float32, [S,nq,k] int64) of the gathered blocks (strided, no copy)."""
+        import torch
+
+        nqk = self.nq * self.k
+        s = self.gathered[:, : 4 * nqk].view(torch.float32).reshape(self.world, self.nq, self.k)
+        i = self.gathered[:, self.idx_offset:].view(torch.int64).reshape(self.world, self.nq, self.k)
+        return s, i
+
+    def merge(self, merge_fn: Optional[Callable] = None):
+        """Global top-k from the gathered blocks; merge_fn(scores[S,nq,k], idx[S,nq,k]) replaces the
+        HIP merge in CPU tests."""
+        if merge_fn is not None:
+            s, i = self.blocks()
+            return merge_fn(s.contiguous(), i.contiguous())
+        from .. import ops
+        return ops.topk_merge_packed(self.gathered, self.world, self.nq, self.k, self.idx_offset, self.merged_s, self.merged_i)
+
+
 class ShardedIndex:
     """This rank's shard of a row-sharded embedding database.
 

@@ -114,6 +114,21 @@ def topk_merge(scores, idx):
     return out_s, out_i
 
 
+def topk_merge_packed(gathered, S: int, nq: int, k: int, idx_offset: int, out_s, out_i):
+    """Merge S packed result blocks [scores f32 nq*k | pad | rows i64 nq*k] laid out back to back in the
+    uint8 buffer ``gathered`` (the all-gather output) without unpacking them."""
+    torch = _lib.require_gpu()
+    if gathered.dtype != torch.uint8 or not gathered.is_cuda or not gathered.is_contiguous():
+        raise MerizoHipError("topk_merge_packed: expected a contiguous uint8 CUDA buffer")
+    stride = gathered.numel() // S
+    if stride * S != gathered.numel() or stride < idx_offset + 8 * nq * k:
+        raise MerizoHipError("topk_merge_packed: buffer size does not match S blocks of nq*k results")
+    base = gathered.data_ptr()
+    check(_lib.load().ms_topk_merge_strided(base, base + idx_offset, stride, stride, S, nq, k, ptr(out_s), ptr(out_i),
+                                            current_stream()), "ms_topk_merge_strided")
+    return out_s, out_i
+
+
 class EgnnEncoder:
     """The Foldclass structure encoder on one GPU: prepared weights + positional table.
 

@@ -93,6 +93,16 @@ idx2 = ShardedIndex(torch.from_numpy(db[lo2:hi2].copy()), lo2, search_fn=lambda 
                     merge_fn=eng.topk_merge)
 s2, i2 = idx2.search(q, k)
 assert np.array_equal(i2.numpy(), i_ref) and np.array_equal(s2.numpy(), s_ref)
+# the serving-loop form: results written straight into this rank's packed block, one all-gather, blocks read in place
+from merizo_search_amd.foldclass.sharded import PackedExchange
+for nq3, k3 in ((17, 10), (5, 3)):                       # nq*k odd too: the int64 half stays 8-byte aligned
+    ex = PackedExchange(nq3, k3, "cpu")
+    s3, i3 = eng.ip_topk(torch.from_numpy(db[lo:hi].copy()), q[:nq3], k3, lo)
+    ex.out_s.copy_(s3); ex.out_i.copy_(i3)
+    ex.exchange()
+    s4, i4 = ex.merge(merge_fn=eng.topk_merge)
+    s_ref3, i_ref3 = orc.ip_topk(db, q[:nq3].numpy(), k3)
+    assert np.array_equal(i4.numpy(), i_ref3) and np.array_equal(s4.numpy(), s_ref3), (rank, "packed exchange")
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 '''

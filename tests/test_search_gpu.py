@@ -179,6 +179,28 @@ def test_topk_merge_shards_equals_unsharded(torch_gpu):
         assert torch.equal(i, i_full) and torch.equal(s, s_full)
 
 
+def test_topk_merge_packed_reads_allgather_blocks_in_place(torch_gpu):
+    """ms_topk_merge_strided on S packed blocks [scores | pad | rows] == ms_topk_merge on dense arrays."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass.sharded import PackedExchange
+    for nq, k, S in ((9, 3, 3), (64, 10, 8)):
+        g = torch.Generator(device="cpu"); g.manual_seed(nq)
+        sc = torch.sort(torch.randn((S, nq, k), generator=g), dim=2, descending=True).values
+        sc[1, :, k - 1] = sc[0, :, k - 1]                                        # ties across shards
+        ix = torch.stack([torch.arange(nq * k, dtype=torch.int64).reshape(nq, k) * S + s for s in range(S)])
+        ix[S - 1, 0, k - 1] = -1; sc[S - 1, 0, k - 1] = float("-inf")             # padding entry
+        ex = PackedExchange(nq, k, "cuda:0")
+        ex.world = S
+        ex.gathered = torch.zeros((S, ex.block_bytes), dtype=torch.uint8, device="cuda:0")
+        for s in range(S):
+            ex.gathered[s, : 4 * nq * k] = sc[s].contiguous().view(torch.uint8).reshape(-1).cuda()
+            ex.gathered[s, ex.idx_offset:] = ix[s].contiguous().view(torch.uint8).reshape(-1).cuda()
+        ms, mi = ex.merge()
+        rs, ri = ops.topk_merge(sc.cuda(), ix.cuda())
+        assert torch.equal(ms, rs) and torch.equal(mi, ri)
+
+
 def test_full_size_properties_c2(torch_gpu):
     """BASELINE config C2 (1M x 128, nq 256, k 10) through size-independent properties:
     planted neighbours are recalled, lists are sorted, scores reproduce from the returned

@@ -1221,12 +1221,18 @@ int head_merge_setting() {
     return v;
 }
 
-int prepass_tiles_setting() {
+int sample_min_queries_setting() {
     static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("MS_PREPASS_TILES");
-        v = e ? atoi(e) : 32;
-        if (v < 0) v = 0;
+    if (v < 0) { const char *e = getenv("MS_SAMPLE_MIN_NQ"); v = e ? atoi(e) : 8; }
+    return v;
+}
+
+int prepass_tiles_setting() {
+    static int v = -2;
+    if (v == -2) {
+        const char *e = getenv("MS_PREPASS_TILES");     // diagnostics: force a sample size (0 = no sample pass)
+        v = e ? atoi(e) : -1;
+        if (v < -1) v = -1;
     }
     return v;
 }
@@ -1263,9 +1269,18 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.lds_bytes = 4 * 32768 + 4 * 1024;
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
+    // Size of the sample: T0 tiles per stream cost T0 tile times; the insertion steps they save in the
+    // full pass fall as 1/T0 (candidates per tile = 1024 k / (streams * 32 * T0) while the sample's bound is
+    // tighter than a stream's own list).  Minimum at T0 = sqrt(c * tiles_per_stream * k / streams), c from
+    // the measured cost of a tile (2.2 us) and of a candidate (0.27 us): 3 tiles at 31 tiles per stream,
+    // 9 at 244, 17 at 977 for k = 10 and 128 streams (sweeps at 125k-16M rows x 256 queries agree).
     pl.prepass_tiles = prepass_tiles_setting();
-    while (pl.prepass_tiles > 1 && tiles_per_stream < 30 * (int64_t)pl.prepass_tiles) pl.prepass_tiles /= 2;   // sample about 1/30 of a stream (measured optimum at 1M-16M rows x 256 queries)
-    if (tiles_per_stream < 12 * (int64_t)pl.prepass_tiles || k > 64 || nq < 16) pl.prepass_tiles = 0;   // few queries: few insertions anyway
+    if (pl.prepass_tiles < 0) {
+        const double t0 = sqrt(0.3 * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
+        pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));
+    }
+    if (tiles_per_stream < 8 * (int64_t)pl.prepass_tiles) pl.prepass_tiles = (int)(tiles_per_stream / 8);
+    if (tiles_per_stream < 12 || k > 64 || nq < sample_min_queries_setting()) pl.prepass_tiles = 0;   // short streams / few queries: few insertions anyway
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);

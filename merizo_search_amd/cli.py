@@ -75,9 +75,14 @@ def _search_and_write(args, inputs, inputs_are_ca, pdb_chain, fields, tmp):
     for path in (search_output, all_output):
         if os.path.exists(path):
             logging.warning(f"Search output file '{path}' already exists. Results will be overwritten!")
+    multi_output = args.output + "_search_multi_dom.tsv"
     if args.multi_domain_search:
-        logging.error("--multi_domain_search is not available in merizo_search_amd (see DESIGN.md, out of scope).")
-        sys.exit(1)
+        if tm.find_tmalign() is None:
+            logging.error("--multi_domain_search aligns every query domain with every candidate target domain and needs a "
+                          "TM-align binary (set $MERIZO_TMALIGN).")
+            sys.exit(1)
+        if os.path.exists(multi_output):
+            logging.warning(f"Multi-domain search output file '{multi_output}' already exists. Results will be overwritten!")
     results, all_results = run_dbsearch(
         inputs=inputs, db_name=args.db_name, tmp=tmp, device=args.device, topk=args.topk, fastmode=args.fastmode,
         threads=args.threads, mincos=args.mincos, mintm=args.mintm, mincov=args.mincov, inputs_are_ca=inputs_are_ca,
@@ -89,6 +94,15 @@ def _search_and_write(args, inputs, inputs_are_ca, pdb_chain, fields, tmp):
     if args.report_insignificant_hits:
         write_search_results(results=all_results, output_file=all_output, format_list=fields, header=args.output_headers,
                              metadata_json=args.metadata_json)
+    if args.multi_domain_search:
+        # merizo.py:207-222 / :396-411.  `search`: the inputs are single-domain files of ONE chain (the reference
+        # passes inputs_from_easy_search=True here, which fails on file names; its stated intent is one chain 'A').
+        from .foldclass.multidomain import multi_domain_search
+        from .foldclass.results import write_all_dom_search_results
+        mda = multi_domain_search(queries=inputs, search_results=results, db_name=args.db_name, tmp_root=tmp, device=args.device,
+                                  fastmode=args.fastmode, threads=args.threads, mintm=args.mintm,
+                                  inputs_from_easy_search=inputs_are_ca, mode=args.multi_domain_mode, pdb_chain=pdb_chain)
+        write_all_dom_search_results(mda, multi_output, args.output_headers)
 
 
 def search(argv) -> None:

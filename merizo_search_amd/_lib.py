@@ -56,7 +56,7 @@ SIGNATURES = {
 
 def build(force: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    cmd = ["make", "-j", str(min(8, os.cpu_count() or 1)), "-C", CSRC] + (["-B"] if force else [])
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise MerizoHipError("hipcc build failed:\n" + proc.stdout + proc.stderr)

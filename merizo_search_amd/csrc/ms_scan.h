@@ -1,0 +1,954 @@
+// Scan kernels of the search path and their launch templates, shared by the translation units that
+// instantiate them (one per list length, so that they compile in parallel): ms_scan_kl5.hip,
+// ms_scan_kl10.hip, ms_scan_kl32.hip, ms_scan_kl32ub.hip.  ms_search.hip holds everything else.
+#pragma once
+#include "ms_common.h"
+
+#include <math.h>
+#include <stdlib.h>
+
+// ------------------------------------------------------------------ scan kernel --------
+struct ScanParams {
+    const float *db;        // [n,128]
+    int64_t n;
+    const float *qn;        // [nq_pad,128] prepared queries
+    int nq;                 // real queries
+    int nq_pad;
+    int k;                  // ranks wanted this pass (<= 2*KL <= 64)
+    const float *inv_norm;  // [n] or NULL
+    const float *lengths;   // [n] or NULL
+    const float *qlen;      // [nq] or NULL
+    float mincov;
+    const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
+    const uint32_t *ub_i;
+    const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
+    int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
+    float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
+    uint32_t *part_i;
+    int rows_per_stream;    // multiple of 32
+    int n_streams;          // row streams (one wave each per query tile)
+    int n_qtiles;           // 32-query tiles
+    int qwb;                // query tiles per workgroup: 4, 2 or 1 (the other 4/qwb waves take other streams)
+    int n_qgroups;
+    int n_sgroups;          // stream groups = workgroups per query group
+    int P;                  // partial lists per query written by this launch
+#ifdef MS_STAMP
+    unsigned long long *stamps;   // diagnostic builds only: per compute wave {cycles, 100 MHz ticks, tiles, 0}
+#endif
+};
+
+// value of `x` in the partner lane (lane ^ 32): one v_permlane32_swap + one select, no LDS
+__device__ __forceinline__ uint32_t ms_xor32_u(uint32_t x, int h) {
+    const auto r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return h ? r[0] : r[1];
+}
+__device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_float(ms_xor32_u(__float_as_uint(x), h)); }
+
+// One wave = one (query tile, row stream) pair, one wave per SIMD; waves never synchronise
+// with each other inside the scan.  The loop over 32-row tiles is software-pipelined around
+// the dependent chain of 64 v_mfma_f32_32x32x2_f32 of tile t (4096 cycles of matrix pipe):
+//   before the chain   s_waitcnt vmcnt(0): tile t+1 has landed in LDS (issued a tile ago);
+//                      LDS-DMA of tile t+2 (global_load_lds_dwordx4, 16 x 1 KiB) into the slot
+//                      tile t just vacated -- lane-linear destination, XOR-swizzled SOURCE;
+//   in the MFMA gaps   16 ds_read_b128 pull tile t+1 into 64 VGPRs (A-fragment order), and the
+//                      filter of tile t-1 runs: one compare per score against the query's k-th
+//                      best so far;
+//   after the chain    the rare insertion steps for tile t-1.
+// The running top-k of query q lives in the REGISTERS of its two lanes (q, q+32): lane q holds
+// ranks 0..KL-1, lane q+32 ranks KL..2KL-1, sorted.  An insertion step handles one database
+// row for all 32 queries at once (SIMD over queries): the candidate goes to lane q, lane q's
+// displaced last entry (one compare tells which) goes to lane q+32, both lanes update their
+// sorted half with one compare and four selects per entry.  No atomics, no cross-wave traffic.
+// (ms_scan_loader_kernel below is the form used for >= 3 query tiles; this one serves 1-2 query
+// tiles -- the HBM-bound regime -- and, with MAXONLY, the sample pass.)
+template <int KL>
+struct ScanState {
+    float ls[KL];
+    uint32_t li[KL];
+    float tau;     // scores must be > tau to matter: max(k-th best so far, floor)
+    float floor;   // largest float below the sample pass's lower bound (-inf without one)
+};
+
+// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
+// one insertion step: the candidate of row `crow` (score v in lanes of half hh whose bit is set
+// in mm) goes into the lists of all 32 queries at once
+template <int KL>
+__device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32_t mm, int hh, uint32_t crow, int r, int h) {
+    // candidate of this lane pair (or -inf); re-checked against the current tau
+    const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
+    const float c = mine ? v : -INFINITY;
+    const float pc = ms_xor32_f(c, h);
+    const float cand = (h == hh) ? c : pc;
+    // lane q+32 receives lane q's last entry if the candidate displaces it
+    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+    const bool spill = (h == 1) && (cand > pl_s);
+    // Sorted insert without a serial compare-exchange chain: with ge[e] = (old ls[e] >= x),
+    //     new ls[e] = ge[e] ? ls[e] : (ge[e-1] ? x : ls[e-1])        (ge[-1] = true)
+    // so every entry needs one compare and two selects per array, all on OLD values (updated in
+    // place from the last entry down).  New rows lose ties (>=: ascending row order).  A spilled
+    // entry is not below anything in lane q+32's half (the pair's list is sorted), so it goes to
+    // position 0: its compare value is NaN (ge false everywhere).  No candidate: x = -inf, ge true.
+    const float x_cmp = spill ? __builtin_nanf("") : cand;
+    const float ins_s = spill ? pl_s : cand;
+    const uint32_t ins_i = spill ? pl_i : crow;
+    bool ge_hi = st.ls[KL - 1] >= x_cmp;
+#pragma unroll
+    for (int e = KL - 1; e >= 1; --e) {
+        const bool ge_lo = st.ls[e - 1] >= x_cmp;
+        const float ns = ge_lo ? ins_s : st.ls[e - 1];
+        const uint32_t ni = ge_lo ? ins_i : st.li[e - 1];
+        st.ls[e] = ge_hi ? st.ls[e] : ns;
+        st.li[e] = ge_hi ? st.li[e] : ni;
+        ge_hi = ge_lo;
+    }
+    st.ls[0] = ge_hi ? st.ls[0] : ins_s;
+    st.li[0] = ge_hi ? st.li[0] : ins_i;
+    const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+}
+
+// insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]; rows in ascending
+// order: row 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
+#ifndef MS_STATIC_INSERT_MAX_KL
+#define MS_STATIC_INSERT_MAX_KL 32
+#endif
+template <int KL>
+__device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
+                                               int64_t sub_row0, int r, int h) {
+    if (KL <= MS_STATIC_INSERT_MAX_KL) {
+        // short lists (k <= 10, the common case): one static copy of the step per row
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if ((m[4 * g] | m[4 * g + 1] | m[4 * g + 2] | m[4 * g + 3]) == 0) continue;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint64_t mj = m[4 * g + j];
+                    const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+                    if (mm == 0) continue;
+                    ms_row_insert<KL>(st, sc[4 * g + j], mm, hh, (uint32_t)(sub_row0 + 8 * g + 4 * hh + j), r, h);
+                }
+            }
+        }
+    } else {
+        // long lists: a single copy of the (32-slot) step inside a runtime loop over the rows keeps
+        // the code size and the build time down
+        for (int row = 0; row < 32; ++row) {
+            const int reg = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
+            uint64_t mj = m[0];
+            float v = sc[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { mj = (reg == i) ? m[i] : mj; v = (reg == i) ? sc[i] : v; }
+            const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
+            if (mm == 0) continue;
+            ms_row_insert<KL>(st, v, mm, hh, (uint32_t)(sub_row0 + row), r, h);
+        }
+    }
+}
+
+template <int KL, bool AUX, bool UB, bool MAXONLY>
+__device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
+    // below becomes 64-bit per-lane arithmetic
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    // two private 32 x 32 float4 tile slots per wave
+    f32x4 *slot0 = reinterpret_cast<f32x4 *>(smem + wave * 32768);
+    // cosine mode: 1/|row| (32 floats) + target lengths (32 floats) of a tile, 4 slots (tile index & 3)
+    float *aux0 = reinterpret_cast<float *>(smem + 4 * 32768 + wave * 1024);
+
+    // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
+    const int bid = blockIdx.x;
+    const int per_super = 8 * p.n_qgroups;
+    const int super = bid / per_super, within = bid % per_super;
+    const int sgroup = super * 8 + (within & 7);
+    const int qg = within >> 3;
+    if (sgroup >= p.n_sgroups) return;
+    const int spb = 4 / p.qwb;
+    const int qw = wave % p.qwb, sw = wave / p.qwb;
+    const int stream = sgroup * spb + sw;
+    const int qtile = qg * p.qwb + qw;
+    const bool active = stream < p.n_streams && qtile < p.n_qtiles;
+
+    ScanState<KL> st;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+    st.floor = -INFINITY;
+#ifdef MS_DEBUG_NO_INSERT
+    st.tau = INFINITY;
+#else
+    st.tau = -INFINITY;
+#endif
+
+    // MAXONLY (sample pass): no lists, only this lane's best row so far (its half of every tile)
+    float smax = -INFINITY;
+    uint32_t srow = MS_IDX_NONE;
+
+    if (active) {
+        const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
+        int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
+        if (p.max_tiles > 0 && row_begin + (int64_t)p.max_tiles * 32 < row_end) row_end = row_begin + (int64_t)p.max_tiles * 32;
+        const int qidx = qtile * 32 + r;
+        const bool q_valid = qidx < p.nq;
+        if (p.lb_s != nullptr) {
+            // s >= lb  <=>  s > nextbelow(lb): at least k sampled rows score >= lb, so anything
+            // below it cannot reach the top k; rows that tie with it still can
+            const float lb = p.lb_s[qidx];
+            st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
+#ifndef MS_DEBUG_NO_INSERT
+            st.tau = st.floor;
+#endif
+        }
+        // padding queries of the last tile never pass the filter: threshold +inf (one compare per score)
+        if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }
+
+        // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
+        float qreg[64];
+        {
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 v = src[t];
+                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+            }
+        }
+        // cosine mode, branch-free: without a lengths array the mask test is +inf >= x * 0
+        float my_qlen = 0.0f;
+        if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+        const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;
+        const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
+        float ubs = INFINITY;
+        uint32_t ubi = 0;
+        if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
+        // LDS-DMA of one tile into slot (t & 1).  Instruction `it` fills float4 slots 64 it .. 64 it + 63,
+        // i.e. rows 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
+        // Per-lane byte offset inside the tile for instruction it:
+        //     (2 it + h) * 512 + 16 * ((r ^ h) ^ (2 it & 15))  =  it * 1024 [scalar] + off8[it & 7]
+        uint32_t off8[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) off8[c] = (uint32_t)(h * 512 + 16 * ((r ^ h) ^ (2 * c)));
+        // cosine mode: one more LDS-DMA piece per tile (4 B per lane): lanes 0-31 fetch 1/|row| of the
+        // tile's rows, lanes 32-63 their lengths (clamped to the last database row), into aux slot t & 3
+        auto issue_aux_dma = [&](int t) {
+            if (!AUX) return;
+            int64_t row = row_begin + (int64_t)t * 32 + r;
+            if (row >= p.n) row = p.n - 1;
+            const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + row),
+                                             (__attribute__((address_space(3))) void *)(aux0 + (t & 3) * 64), 4, 0, 0);
+        };
+        auto issue_dma = [&](int t) {
+            issue_aux_dma(t);
+            const int64_t row0 = row_begin + (int64_t)t * 32;
+            f32x4 *dst = slot0 + (t & 1) * 1024;
+            const char *tile_src = reinterpret_cast<const char *>(p.db) + row0 * 512;
+            if (row0 + 32 <= p.n) {
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const char *src = tile_src + it * 1024 + off8[it & 7];
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
+                }
+            } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    int64_t row = row0 + 2 * it + h;
+                    if (row >= p.n) row = p.n - 1;
+                    const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
+                }
+            }
+        };
+
+        // Scores of registers 4g..4g+3 of a finished tile -> sc (cosine mode: * 1/|row|, * length
+        // mask) and pass masks.  Branch-free so that it can sit between the MFMAs of the next
+        // tile; CHECK_ROWS (row < row_end) is only needed for the last tile of a stream, which is
+        // filtered in the drain.
+        auto filter_group = [&](const f32x16 &acc, int64_t sub_row0, int g, bool check_rows, float (&sc)[16],
+                                uint64_t (&m)[16]) {
+            const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+            f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (AUX) {
+                // the group's 4 row scales and 4 row lengths: two ds_read_b128.  Tile index from its first
+                // row; before the first tile (sub_row0 < row_begin, scores are -inf) any slot will do
+                const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
+                const f32x4 *ax = reinterpret_cast<const f32x4 *>(aux0 + tix * 64 + 8 * g + 4 * h);
+                inv4 = ax[0];
+                len4 = ax[8];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = acc[4 * g + j];
+                if (AUX) {
+                    float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8)
+                    const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;           // dbsearch.py:76
+                    sv = sv * mk;                                                                // dbsearch.py:78
+                    s = (sub_row0 >= row_begin) ? sv : -INFINITY;   // "tile -1" of the pipeline has no aux data
+                }
+                sc[4 * g + j] = s;
+                if (MAXONLY) {      // strict >: the lowest row wins ties; -inf / NaN scores never enter
+                    bool ok = s > smax;
+                    if (check_rows) ok = ok && (rbase + j < row_end);
+                    smax = ok ? s : smax;
+                    srow = ok ? (uint32_t)(rbase + j) : srow;
+                    m[4 * g + j] = 0;
+                    continue;
+                }
+                bool pass = s > st.tau;
+                if (check_rows) pass = pass && (rbase + j < row_end);
+                if (UB) {
+                    const uint32_t lrow = (uint32_t)(rbase + j);
+                    pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
+                }
+                m[4 * g + j] = __ballot(pass);
+            }
+        };
+
+        // one pipeline stage: MFMA chain of tile t from `areg`; each fragment register is
+        // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
+        // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
+        f32x4 areg[16];
+        const int nfull = (int)((row_end - row_begin) >> 5);       // full 32-row tiles: the pipelined loop
+        const int rem = (int)((row_end - row_begin) & 31);          // partial last tile: handled after it
+        auto stage = [&](int t, const f32x16 &prev, f32x16 &out) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slot t&1 (tile t) fully read into areg
+            const f32x4 *src = slot0 + ((t + 1) & 1) * 1024 + r * 32;
+            const int64_t prev_row0 = row_begin + (int64_t)(t - 1) * 32;
+            // LDS-DMA of tile t+2 (past the end: a harmless re-read of the last tile) into the slot tile t
+            // vacated, one piece per MFMA group so that its issue time hides behind the matrix pipe
+            const int tnext = (t + 2 < nfull) ? t + 2 : nfull - 1;
+            const char *dma_src = reinterpret_cast<const char *>(p.db) + (row_begin + (int64_t)tnext * 32) * 512;
+            f32x4 *dma_dst = slot0 + (t & 1) * 1024;
+            float sc[16];
+            uint64_t m[16];
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const f32x4 a = areg[tt];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                // tile t+1 was issued during the previous chain: it only has to have landed by the middle
+                // of this one.  vmcnt(8): everything but the 8 pieces of tile t+2 issued so far.
+                if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
+                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
+                if (tt == 15) issue_aux_dma(tnext);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+                if (tt >= 8) {   // refill the fragment registers of groups 2(tt-8), 2(tt-8)+1 (already consumed) with tile t+1
+                    const int f0 = 2 * (tt - 8);
+                    areg[f0] = src[(16 * h + f0) ^ (r & 15)];
+                    areg[f0 + 1] = src[(16 * h + f0 + 1) ^ (r & 15)];
+                }
+                if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
+            }
+            out = acc;
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+        };
+
+        f32x16 last;   // scores of the tile whose candidates are not inserted yet
+#pragma unroll
+        for (int i = 0; i < 16; ++i) last[i] = -INFINITY;
+        int64_t last_row0 = row_begin;
+        if (nfull > 0) {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
+            issue_dma(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            issue_dma(1);                   // into slot 1; tile 1 may be past the end: clamped reads, never used
+            int t = 0;
+            for (; t + 1 < nfull; t += 2) {
+                stage(t, acc0, acc1);       // acc0 = scores of tile t-1 (or -inf), acc1 <- tile t
+                stage(t + 1, acc1, acc0);   // acc1 = tile t, acc0 <- tile t+1
+            }
+            if (t < nfull) {                // odd tail
+                stage(t, acc0, acc1);
+                acc0 = acc1;
+            }
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // stray prefetches done
+            last = acc0;
+            last_row0 = row_begin + (int64_t)(nfull - 1) * 32;
+        }
+        if (nfull > 0) {   // filter + insert the last full tile
+            float sc[16];
+            uint64_t m[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) filter_group(last, last_row0, g, true, sc, m);
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, last_row0, r, h);
+        }
+        if (rem > 0) {                      // partial last tile of the stream, not pipelined
+            issue_dma(nfull);               // -> slot nfull & 1; rows past the database end are clamped
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const f32x4 *src = slot0 + (nfull & 1) * 1024 + r * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const f32x4 a = src[(16 * h + tt) ^ (r & 15)];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+            }
+            float sc[16];
+            uint64_t m[16];
+            const int64_t tail_row0 = row_begin + (int64_t)nfull * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) filter_group(acc, tail_row0, g, true, sc, m);
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, tail_row0, r, h);
+        }
+    }
+    if (MAXONLY && active) {
+        // the stream's list = the two half-tile maxima of the lane pair (distinct rows), best first,
+        // in lane q; lane q+32 stays empty
+        const float ps2 = ms_xor32_f(smax, h);
+        const uint32_t pr2 = ms_xor32_u(srow, h);
+        if (h == 0) {
+            const bool mine_first = ms_better(smax, srow, ps2, pr2);
+            st.ls[0] = mine_first ? smax : ps2; st.li[0] = mine_first ? srow : pr2;
+            st.ls[1] = mine_first ? ps2 : smax; st.li[1] = mine_first ? pr2 : srow;
+            if (st.li[0] == MS_IDX_NONE) st.ls[0] = -INFINITY;
+            if (st.li[1] == MS_IDX_NONE) st.ls[1] = -INFINITY;
+        }
+    }
+    const int KLc = KL;
+    float (&ls)[KL] = st.ls;
+    uint32_t (&li)[KL] = st.li;
+    (void)KLc;
+
+    // ---- write the lists.  qwb == 4: one partial list per (stream, query).  qwb < 4: the
+    //      4/qwb streams of a query tile inside this workgroup are merged through LDS first. ----
+    constexpr int K2 = 2 * KL;
+    if (p.qwb == 4) {
+        if (!active) return;
+        const int qidx = qtile * 32 + r;
+#pragma unroll
+        for (int j = 0; j < KL; ++j) {
+            const int rank = h * KL + j;
+            if (rank < p.k) {
+                const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+                p.part_s[o] = ls[j];
+                p.part_i[o] = li[j];
+            }
+        }
+        return;
+    }
+    __syncthreads();                                   // every wave is done with its tile slot
+    uint2 *lists = reinterpret_cast<uint2 *>(smem);    // [qw][sw][32 queries][K2]
+    {
+        uint2 *mine = lists + ((size_t)(qw * spb + sw) * 32 + r) * K2 + h * KL;
+#pragma unroll
+        for (int j = 0; j < KL; ++j) mine[j] = make_uint2(__float_as_uint(ls[j]), li[j]);
+    }
+    __syncthreads();
+    for (int pair = wave; pair < p.qwb * 32; pair += 4) {
+        const int pqw = pair >> 5, pq = pair & 31;
+        uint2 *dst = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;
+        for (int s2 = 1; s2 < spb; ++s2) {
+            const uint2 *src = lists + ((size_t)(pqw * spb + s2) * 32 + pq) * K2;
+            const uint2 e = (lane < K2) ? src[lane] : make_uint2(0u, MS_IDX_NONE);
+            const uint2 last = dst[K2 - 1];
+            const bool cand = lane < K2 && e.y != MS_IDX_NONE &&
+                              ms_better(__uint_as_float(e.x), e.y, __uint_as_float(last.x), last.y);
+            const int c = __popcll(__ballot(cand));   // sorted source: survivors form a prefix
+            for (int i = 0; i < c; ++i)
+                ms_wave_insert(dst, K2, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < p.qwb * 32 * p.k; e += 256) {
+        const int lq = e / p.k, rank = e % p.k;        // lq = qw*32 + q
+        const int pqw = lq >> 5, pq = lq & 31;
+        const int qt = qg * p.qwb + pqw;
+        if (qt >= p.n_qtiles) continue;
+        const uint2 v = lists[((size_t)(pqw * spb) * 32 + pq) * K2 + rank];
+        const size_t o = ((size_t)(qt * 32 + pq) * p.k + rank) * p.P + sgroup;
+        p.part_s[o] = __uint_as_float(v.x);
+        p.part_i[o] = v.y;
+    }
+}
+
+// ------------------------------------------------------------------ scan, loader-wave form
+// MFMA-bound batches (>= 3 query tiles, qwb == 4): the 4 compute waves of a workgroup scan the
+// SAME rows for 4 query tiles.  In ms_scan_body each of them fetches its own copy of every tile,
+// and the 16 LDS-DMA pieces per tile cost the issuing wave about 60 cycles each inside its MFMA
+// chain (4.1k -> 5.2k cycles per tile, in-kernel stamps).  Here a FIFTH wave does nothing but the
+// LDS-DMA: one copy of each tile into a ring of LDR_R slots shared by the workgroup, up to
+// LDR_D tiles in flight (counted s_waitcnt vmcnt), published through flag words in LDS; the
+// compute waves poll the flag of tile t+1 in the middle of chain t and report what they have
+// consumed.  No barrier: a wave delayed by insertions may trail the others by LDR_R - 1 tiles
+// before the loader has to wait for it.  (The kernel needs <= 256 registers per wave so that
+// the loader can share a SIMD with a compute wave: __launch_bounds__(320, 2).)
+constexpr int LDR_R = 4;        // ring slots (tiles)
+constexpr int LDR_D = 3;        // tiles the loader keeps in flight before publishing the oldest
+constexpr int LDR_AUX = 8;      // aux (row scale / length) ring: a tile's aux data outlives its slot by two stages
+constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
+
+// LDS-DMA pieces as inline asm (the loader wave sets M0 itself; nothing else in that wave uses M0):
+// 64 lanes x 16 B (or 4 B) from global memory to LDS bytes lds_addr + lane * size.
+__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void ms_glds_v16(uint32_t lds_addr, const void *lane_ptr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+}
+__device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+}
+
+template <bool AUX, int N>
+__device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N tiles' worth of DMA pieces are in flight
+    constexpr int P = AUX ? 17 : 16;
+    if (N * P == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (N * P == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (N * P == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+    else if (N * P == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if (N * P == 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 compute, 4 loader
+    const int r = lane & 31, h = lane >> 5;
+    // smem: LDR_R tile slots of 32 x 32 float4, then the aux ring, then the flag words
+    float *auxring = reinterpret_cast<float *>(smem + LDR_R * 16384);                 // LDR_AUX x 64 floats
+    // flag words, as explicit LDS (address space 3) pointers: a volatile access through a generic
+    // pointer compiles to flat_load + s_waitcnt vmcnt(0), hundreds of cycles in the middle of a chain
+    typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
+    lds_flag_t *full = (lds_flag_t *)(smem + LDR_R * 16384 + LDR_AUX * 256);          // [LDR_R] tile+1 held by the slot
+    lds_flag_t *consumed = full + 8;                                                   // [4] tiles read by compute wave w
+
+    const int bid = blockIdx.x;
+    const int per_super = 8 * p.n_qgroups;
+    const int super = bid / per_super, within = bid % per_super;
+    const int stream = super * 8 + (within & 7);      // qwb == 4: one stream per workgroup
+    const int qg = within >> 3;
+    if (stream >= p.n_streams) return;
+    const int64_t row_begin = (int64_t)stream * p.rows_per_stream;
+    const int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
+    const int nfull = (int)((row_end - row_begin) >> 5);
+    const int rem = (int)((row_end - row_begin) & 31);
+    const int ntl = nfull + (rem > 0 ? 1 : 0);        // tiles the loader delivers (the last one may be partial)
+
+    if (tid < 16) {
+        uint32_t v = 0;
+        if (tid >= 8 && tid < 12) v = ((qg * 4 + (tid - 8)) < p.n_qtiles) ? 0u : 0xFFFFFFFFu;   // padding query tiles never block the loader
+        full[tid] = v;
+    }
+    __syncthreads();
+
+    if (wave == 4) {
+        // ---------------- loader ----------------
+#ifdef MS_ABL_NOFLAG
+        if (lane == 0) for (int i = 0; i < LDR_R; ++i) full[i] = 0x7FFFFFFFu;
+        return;
+#endif
+        // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs
+        // back to back, so it is written to need as few instructions as possible: raised priority,
+        // and every LDS-DMA piece is one s_mov m0 + one global_load_lds with an SGPR base and a
+        // precomputed 32-bit lane offset (inline asm: hipcc's builtin form spends 2-5 VALU
+        // instructions per piece on 64-bit lane addresses).
+        __builtin_amdgcn_s_setprio(3);
+        uint32_t voff[16];
+#pragma unroll
+        for (int it = 0; it < 16; ++it) voff[it] = (uint32_t)(it * 1024 + h * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
+        const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
+        const uint32_t aux_lds = ring_lds + LDR_R * 16384;
+#ifdef MS_STAMP
+        unsigned long long lst_poll = 0, lst_issue = 0, lst_vm = 0, lst_t0 = __builtin_amdgcn_s_memtime();
+#define LST(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc += now_ - lst_t0; lst_t0 = now_; }
+#else
+#define LST(acc)
+#endif
+        for (int t = 0; t < ntl; ++t) {
+            if (t >= LDR_R) {                          // slot t % R is free once everybody has read tile t - R
+                const uint32_t need = (uint32_t)(t - LDR_R + 1);
+                for (uint32_t spins = 0;; ++spins) {
+                    const uint32_t c0 = consumed[0], c1 = consumed[1], c2 = consumed[2], c3 = consumed[3];
+                    const uint32_t m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
+                    if (__builtin_amdgcn_readfirstlane(m01 < m23 ? m01 : m23) >= need) break;
+                    if (spins > (1u << 24)) __builtin_trap();     // never a silent hang
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            LST(lst_poll)
+            const int64_t row0 = row_begin + (int64_t)t * 32;
+            const uint32_t slot_lds = ring_lds + (uint32_t)(t % LDR_R) * 16384u;
+            if (AUX) {
+                int64_t row = row0 + r;
+                if (row >= p.n) row = p.n - 1;
+                const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+                ms_glds_v4(aux_lds + (uint32_t)(t % LDR_AUX) * 256u, base + row);
+            }
+            if (row0 + 32 <= p.n) {
+                const uint64_t b = (uint64_t)(uintptr_t)p.db + (uint64_t)row0 * 512u;
+                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);        // (the builtin returns int:
+                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));  //  no sign extension)
+                const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+#pragma unroll
+                for (int it = 0; it < 16; ++it) ms_glds_s16(slot_lds + it * 1024, voff[it], sb);
+            } else {       // last tile of the database: clamp rows past the end (their scores are discarded)
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    int64_t row = row0 + 2 * it + h;
+                    if (row >= p.n) row = p.n - 1;
+                    ms_glds_v16(slot_lds + it * 1024,
+                                reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
+                }
+            }
+            LST(lst_issue)
+            if (t >= LDR_D - 1) {                      // tile t - (D-1) has landed: publish it
+                ms_vmcnt_tiles<AUX, LDR_D - 1>();
+                const int tp = t - (LDR_D - 1);
+                if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+            }
+            LST(lst_vm)
+        }
+#ifdef MS_STAMP
+        if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+            unsigned long long *o = p.stamps + ((size_t)bid * 8 + 4) * 8;
+            o[0] = lst_poll; o[1] = lst_issue; o[2] = lst_vm; o[3] = (unsigned long long)ntl;
+        }
+#endif
+        // drain: publish the last D-1 tiles
+        if (ntl >= 2) {
+            ms_vmcnt_tiles<AUX, 1>();
+            const int tp = ntl - 2;
+            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+        }
+        if (ntl >= 1) {
+            ms_vmcnt_tiles<AUX, 0>();
+            const int tp = ntl - 1;
+            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+        }
+        return;
+    }
+
+    // ---------------- compute waves ----------------
+    const int qtile = qg * 4 + wave;
+    if (qtile >= p.n_qtiles) return;
+    ScanState<KL> st;
+#pragma unroll
+    for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+    st.floor = -INFINITY;
+#ifdef MS_DEBUG_NO_INSERT
+    st.tau = INFINITY;
+#else
+    st.tau = -INFINITY;
+#endif
+    const int qidx = qtile * 32 + r;
+    const bool q_valid = qidx < p.nq;
+    if (p.lb_s != nullptr) {
+        const float lb = p.lb_s[qidx];
+        st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
+#ifndef MS_DEBUG_NO_INSERT
+        st.tau = st.floor;
+#endif
+    }
+    if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
+    float qreg[64];
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const f32x4 v = src[t];
+            qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+        }
+    }
+    float my_qlen = 0.0f;
+    if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+    const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;      // no lengths: +inf >= x * 0
+    const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
+    float ubs = INFINITY;
+    uint32_t ubi = 0;
+    if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
+
+    auto wait_tile = [&](int t) {          // until the loader has published tile t
+        const uint32_t need = (uint32_t)(t + 1);
+        for (uint32_t spins = 0; __builtin_amdgcn_readfirstlane(full[t % LDR_R]) < need; ++spins) {
+            if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
+    auto filter_group = [&](const f32x16 &acc, int t, int g, bool check_rows, float (&sc)[16], uint64_t (&m)[16]) {
+        const int64_t sub_row0 = row_begin + (int64_t)t * 32;
+        const int64_t rbase = sub_row0 + 8 * g + 4 * h;
+        f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (AUX) {          // the group's 4 row scales and 4 row lengths: two ds_read_b128
+            const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
+            inv4 = ax[0];
+            len4 = ax[8];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[4 * g + j];
+            if (AUX) {
+                float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8)
+                const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;           // dbsearch.py:76
+                sv = sv * mk;                                                                // dbsearch.py:78
+                s = (t >= 0) ? sv : -INFINITY;     // "tile -1" of the pipeline has no aux data
+            }
+            sc[4 * g + j] = s;
+            bool pass = s > st.tau;
+            if (check_rows) pass = pass && (rbase + j < row_end);
+            if (UB) {
+                const uint32_t lrow = (uint32_t)(rbase + j);
+                pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
+            }
+            m[4 * g + j] = __ballot(pass);
+        }
+    };
+    // Inside the pipeline (full tiles, no upper bound) the filter is cheaper still: final scores of
+    // group g -> sc, and the lane's running maximum over the tile; ONE compare per tile decides
+    // whether any of the 32 x 32 scores can matter, the per-score ballots are taken only then.
+    auto scale_group = [&](f32x16 &acc, int t, int g, float &mx) {       // in place: acc <- final scores
+        f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (AUX) {
+            const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
+            inv4 = ax[0];
+            len4 = ax[8];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float s = acc[4 * g + j];
+            if (AUX) {
+                float sv = s * inv4[j];
+                const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;
+                sv = sv * mk;
+                s = (t >= 0) ? sv : -INFINITY;
+                acc[4 * g + j] = s;
+            }
+        }
+        mx = fmaxf(mx, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
+    };
+
+    f32x4 areg[16];
+    const uint32_t frag_a0 = (uint32_t)(r * 512 + 256 * h + 16 * (r & 15));    // fragment 0 of this lane inside a slot
+#ifdef MS_STAMP
+    unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
+#endif
+    auto stage = [&](int t, f32x16 &prev, f32x16 &out) {       // prev (raw scores of tile t-1) is scaled in place
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
+#ifndef MS_ABL_NOFLAG
+        if (lane == 0) consumed[wave] = (uint32_t)(t + 1);
+#endif
+        // fragment f of this lane's row sits at float4 column (16 h + f) ^ (r & 15) of the slot:
+        // byte address = (slot + frag_a0) ^ (16 f) -- ONE address register and one v_xor per read
+        // instead of 16 precomputed lane offsets (the slot base has no bits below 2^14)
+        const uint32_t src_a0 = (uint32_t)(((t + 1) % LDR_R) * 16384) + frag_a0;
+        float sc[16];
+        uint64_t m[16];
+        float mx = -INFINITY;
+        uint32_t flag = 0;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const f32x4 a = areg[tt];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+#ifndef MS_ABL_NOFILTER
+            if (tt >= 2 && tt < 6) {
+                if (UB) filter_group(prev, t - 1, tt - 2, false, sc, m);
+                else scale_group(prev, t - 1, tt - 2, mx);
+            }
+#else
+            if (tt == 2) { for (int i = 0; i < 16; ++i) { m[i] = 0; sc[i] = 0.0f; asm volatile("" :: "v"(prev[i])); } }
+#endif
+#ifndef MS_ABL_NOFLAG
+            if (tt == 4) {      // flag of tile t+1: read issued here, looked at three groups later (asm: hipcc would sink the read to its use)
+                const uint32_t fa = (uint32_t)(uintptr_t)(full + (t + 1) % LDR_R);     // LDS byte address
+                asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(fa) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
+        }
+#ifndef MS_ABL_NOFLAG
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) : : "memory");
+        flag = __builtin_amdgcn_readfirstlane(flag);
+#ifdef MS_STAMP
+        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) {
+            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+            wait_tile(t + 1);
+            stamp_wait += __builtin_amdgcn_s_memtime() - w0;
+            stamp_nwait += 1;
+        }
+#else
+        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) wait_tile(t + 1);   // normally long since published
+#endif
+#endif
+#pragma unroll
+        for (int tt = 8; tt < 16; ++tt) {
+            const f32x4 a = areg[tt];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
+#ifndef MS_ABL_NOREFILL
+            const int f0 = 2 * (tt - 8);        // fragments of groups already consumed <- tile t+1
+            areg[f0] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * f0)));
+            areg[f0 + 1] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * (f0 + 1))));
+#endif
+        }
+        out = acc;
+        if (UB) {
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+        } else if (__ballot(mx > st.tau) != 0) {
+#ifdef MS_STAMP
+            const unsigned long long i0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
+            ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+#ifdef MS_STAMP
+            stamp_ins += __builtin_amdgcn_s_memtime() - i0;
+            stamp_nins += 1;
+#endif
+        }
+    };
+
+#ifdef MS_STAMP
+    const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (ntl > 0) {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
+        wait_tile(0);
+#pragma unroll
+        for (int tt = 0; tt < 16; ++tt) areg[tt] = *reinterpret_cast<const f32x4 *>(smem + (frag_a0 ^ (uint32_t)(16 * tt)));
+        // every tile, the partial last one included, goes through the pipeline; its rows past
+        // row_end are rejected by the filter of the last stage / the drain below
+        int t = 0;
+        for (; t + 1 < ntl; t += 2) {
+            stage(t, acc0, acc1);
+            stage(t + 1, acc1, acc0);
+        }
+        if (t < ntl) {
+            stage(t, acc0, acc1);
+            acc0 = acc1;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) consumed[wave] = 0xFFFFFFFFu;
+        float sc[16];
+        uint64_t m[16];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) filter_group(acc0, ntl - 1, g, true, sc, m);
+        uint64_t any = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) any |= m[i];
+        if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
+    }
+#ifdef MS_STAMP
+    if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+        unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;
+        o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
+        o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        o[2] = (unsigned long long)ntl;
+        o[3] = (stamp_nwait << 40) | stamp_wait;
+        o[4] = stamp_ins; o[5] = stamp_nins;
+    }
+#endif
+#pragma unroll
+    for (int j = 0; j < KL; ++j) {
+        const int rank = h * KL + j;
+        if (rank < p.k) {
+            const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+            p.part_s[o] = st.ls[j];
+            p.part_i[o] = st.li[j];
+        }
+    }
+}
+
+// The full scan and the sample pass run the same body; two symbols so that profiles tell them apart.
+template <int KL, bool AUX, bool UB>
+__global__ __launch_bounds__(256, 1) void ms_scan_kernel(const ScanParams p) { ms_scan_body<KL, AUX, UB, false>(p); }
+template <int KL, bool AUX>
+__global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams p) { ms_scan_body<KL, AUX, false, true>(p); }
+
+// ------------------------------------------------------------------ launch plan + launch templates
+struct ScanPlan {
+    int n_qtiles, qwb, n_qgroups, nq_pad;
+    int k_pass;            // ranks per pass (<= 64)
+    int kl;                // list entries per lane: smallest of {5,10,32} with 2*kl >= k_pass
+    int rows_per_stream, n_streams, n_sgroups, P;
+    int grid;
+    int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
+    size_t lds_bytes;
+    // workspace carve (byte offsets)
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, total;
+};
+
+inline int loader_wave_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_LOADER_WAVE"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+template <int KL, bool AUX, bool UB>
+int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    if (!UB && sp.max_tiles > 0) {      // sample pass
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_sample_kernel<KL, AUX>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+        hipLaunchKernelGGL((ms_scan_sample_kernel<KL, AUX>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+        MS_LAUNCH_CHECK("ms_scan_sample_kernel");
+        return MS_OK;
+    }
+    if constexpr (KL <= 10 && !UB) {    // loader-wave form: short lists only (its compute waves must fit 256 registers)
+        if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, UB>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            MS_LAUNCH_CHECK("ms_scan_loader_kernel");
+            return MS_OK;
+        }
+    }
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_kernel<KL, AUX, UB>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
+    hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
+    MS_LAUNCH_CHECK("ms_scan_kernel");
+    return MS_OK;
+}
+
+template <int KL, bool UB>
+int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
+    return aux ? launch_scan_variant<KL, true, UB>(pl, sp, st) : launch_scan_variant<KL, false, UB>(pl, sp, st);
+}
+
+// One non-template entry point per list length (defined in ms_scan_kl*.hip).
+int ms_launch_scan_kl5(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
+int ms_launch_scan_kl10(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
+int ms_launch_scan_kl32(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
+int ms_launch_scan_kl32ub(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);

@@ -93,5 +93,23 @@ int main() {
     run<1>("two interleaved chains of 32", in, out, st, blocks, iters);
     run<2>("single chain + 16 ds_read_b128 (pinned)", in, out, st, blocks, iters);
     run<3>("single chain + 16 ds_read_b128 (compiler)", in, out, st, blocks, iters);
+    // sustained rate: ~2 s of back-to-back launches of the pure chain, wall-clocked with events
+    {
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        const int big = 20000, launches = 300;
+        for (int w = 0; w < 20; ++w) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, in, out, st, big);
+        hipEventRecord(e0);
+        for (int w = 0; w < launches; ++w) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(256), 0, 0, in, out, st, big);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = (double)launches * blocks * 4 * (double)big * 64 * 4096.0;
+        std::vector<unsigned long long> h(blocks * 8);
+        hipMemcpy(h.data(), st, blocks * 8 * 8, hipMemcpyDeviceToHost);
+        printf("sustained %.2f s of the single chain on all SIMDs: %.1f TFLOP/s (%.1f%% of 157.3), in-kernel clock %.3f GHz, %.2f cycles/MFMA\n",
+               ms / 1e3, flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 157.3e12 * 100, (double)h[0] / h[1] * 0.1, (double)h[0] / (64.0 * big));
+    }
     return 0;
 }

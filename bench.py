@@ -11,7 +11,9 @@ query batch: normalised queries -> fused Q.D^T + top-k scan of the resident shar
 the per-chunk lists [-> RCCL all-gather of per-shard top-k + shard merge when N > 1].
 With N > 1 the SAME database is row-sharded over the ranks (strong scaling: total work fixed).
 The database and the queries are resident in HBM before the timed region starts.
-`--rows 365000000 --nq 4096` runs the TED-scale shape (C4).
+`--rows 365000000 --nq 4096` runs the TED-scale shape (C4).  `--streams 2` keeps two query batches
+in flight on two HIP streams (batch i+1's short kernels fill the tail of batch i's scan: +5 % q/s
+at C2); the default is one, so that the HIP-event duration of the scan launch is that kernel alone.
 
 One JSON line is printed by rank 0 (contract in the task statement), with
   roofline     for the dominant kernel (ms_scan_loader_kernel; ms_scan_kernel for < 3 query tiles):
@@ -46,6 +48,9 @@ def main():
     ap.add_argument("--nq", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="query batches in flight: consecutive steps alternate over this many HIP streams, each with its own "
+                         "workspace (batch i+1's short kernels fill the tail of batch i's scan)")
     args = ap.parse_args()
 
     import torch
@@ -88,23 +93,31 @@ def main():
     if mine.any():
         db[(flat_rows[mine] - lo).to(dev)] = planted.reshape(-1, 128)[mine].to(dev)
 
-    ws = ops.TopKWorkspace(dev).get(n_local, nq, k)
-    ex = PackedExchange(nq, k, dev)        # this rank's results are written straight into its all-gather block
-    out_s, out_i = ex.out_s, ex.out_i
+    n_pipes = max(1, args.streams)
+    pipes = []
+    for _ in range(n_pipes):
+        ex = PackedExchange(nq, k, dev)    # this rank's results are written straight into its all-gather block
+        pipes.append({"ws": torch.empty_like(ops.TopKWorkspace(dev).get(n_local, nq, k)), "ex": ex,
+                      "stream": torch.cuda.Stream(device=dev) if n_pipes > 1 else torch.cuda.current_stream(dev)})
     shard_merge = ops.topk_merge
+    step_no = [0]
 
     def step(events=None):
-        ops.ip_topk_prepare(db, q, k, ws)                               # queries + sample pass (lower bound)
-        if events is not None:
-            events[0].record()
-        ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE scan launch
-        if events is not None:
-            events[1].record()
-        ops.ip_topk_finish(n_local, nq, k, ws, out_s, out_i, row_offset=lo)
-        if world > 1:
-            ex.exchange()                                                   # ONE RCCL all-gather of 12*nq*k bytes per rank
-            return ex.merge()                                               # merge of the S blocks in place
-        return out_s, out_i
+        pipe = pipes[step_no[0] % n_pipes]
+        step_no[0] += 1
+        ws, ex = pipe["ws"], pipe["ex"]
+        with torch.cuda.stream(pipe["stream"]):
+            ops.ip_topk_prepare(db, q, k, ws)                               # queries + sample pass (lower bound)
+            if events is not None:
+                events[0].record()
+            ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE scan launch
+            if events is not None:
+                events[1].record()
+            ops.ip_topk_finish(n_local, nq, k, ws, ex.out_s, ex.out_i, row_offset=lo)
+            if world > 1:
+                ex.exchange()                                               # ONE RCCL all-gather of 12*nq*k bytes per rank
+                return ex.merge()                                           # merge of the S blocks in place
+            return ex.out_s, ex.out_i
 
     def fence():
         torch.cuda.synchronize()
@@ -174,7 +187,7 @@ def main():
                        if (n_total, nq) == (1_000_000, 256) else ("cosine top-%d, %d x 128 fp32 synthetic DB, batch=%d queries" % (k, n_total, nq)),
                        "db_rows": n_total, "dim": 128, "queries_per_step": nq, "k": k, "score": "inner product of unit rows",
                        "sharding": "contiguous row shards, %d rows/GPU, RCCL all-gather of per-shard top-k" % n_local if world > 1 else "single shard"},
-            "recall_at_k": recall, "topk_exact_on_sample": exact,
+            "recall_at_k": recall, "topk_exact_on_sample": exact, "batches_in_flight": n_pipes,
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

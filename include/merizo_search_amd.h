@@ -74,7 +74,8 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
 
 /* The three stages of ms_ip_topk for k <= 64, exposed so that a profiler / bench can time the
  * scan kernel alone.  Call them in order with identical arguments:
- *   ms_ip_topk_prepare  queries -> padded (cosine: normalised) copy, inverse row norms if absent,
+ *   ms_ip_topk_prepare  cosine mode: queries -> normalised padded copy (inner-product mode reads the
+ *                       caller's 16-byte aligned array in place), inverse row norms if absent,
  *                       and the sample pass (best rows of the first tiles of every row stream -> a
  *                       lower bound on each query's k-th best score);
  *   ms_ip_topk_scan     ONE launch of the fused score + top-k scan over all remaining rows

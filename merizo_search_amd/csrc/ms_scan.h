@@ -11,7 +11,7 @@
 struct ScanParams {
     const float *db;        // [n,128]
     int64_t n;
-    const float *qn;        // [nq_pad,128] prepared queries
+    const float *qn;        // prepared queries [nq_pad,128], or the caller's [nq,128] array (inner-product mode, 16-byte aligned)
     int nq;                 // real queries
     int nq_pad;
     int k;                  // ranks wanted this pass (<= 2*KL <= 64)
@@ -209,10 +209,12 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
         float qreg[64];
         {
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+            // p.qn may be the caller's own [nq,128] array (inner-product mode): rows past nq read as zeros
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const f32x4 v = src[t];
+                f32x4 v = src[t];
+                if (!q_valid) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
             }
         }
@@ -672,10 +674,11 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
     float qreg[64];
     {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)qidx * MS_DIM + 64 * h);
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const f32x4 v = src[t];
+            f32x4 v = src[t];
+            if (!q_valid) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};     // (p.qn may be the caller's own [nq,128] array)
             qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
         }
     }

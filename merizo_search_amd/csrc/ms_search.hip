@@ -460,11 +460,16 @@ extern "C" int ms_debug_stamps(unsigned long long *host, int words) {
 }
 #endif
 
-void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, int nq, const float *inv_norm, const float *lengths,
+// Inner-product mode uses the queries as given: the scan kernels read the caller's array directly
+// (no padded copy, one launch less per batch) when it is 16-byte aligned.
+bool queries_used_in_place(const float *q, int mode) { return mode == MS_MODE_IP_PRENORM && ((uintptr_t)q & 15) == 0; }
+
+void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const float *q, int nq, const float *inv_norm, const float *lengths,
                       const float *qlen, float mincov, char *ws, int mode, ScanParams *sp) {
     const float *inv = inv_norm;
     if (mode == MS_MODE_COSINE_RAW && inv == nullptr && n > 0) inv = reinterpret_cast<const float *>(ws + pl.off_inv);
-    sp->db = db; sp->n = n; sp->qn = reinterpret_cast<const float *>(ws + pl.off_qn); sp->nq = nq; sp->nq_pad = pl.nq_pad;
+    sp->db = db; sp->n = n; sp->nq = nq; sp->nq_pad = pl.nq_pad;
+    sp->qn = queries_used_in_place(q, mode) ? q : reinterpret_cast<const float *>(ws + pl.off_qn);
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
@@ -501,10 +506,12 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
 int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q, int nq, int mode,
                  const float *inv_norm, const float *lengths, const float *qlen, float mincov, char *ws,
                  hipStream_t st, ScanParams *sp) {
-    float *qn = reinterpret_cast<float *>(ws + pl.off_qn);
-    hipLaunchKernelGGL(ms_prepare_queries_kernel, dim3((pl.nq_pad + 3) / 4), dim3(256), 0, st, q, nq, pl.nq_pad,
-                       mode == MS_MODE_COSINE_RAW ? 1 : 0, 1e-8f, qn);
-    MS_LAUNCH_CHECK("ms_prepare_queries_kernel");
+    if (!queries_used_in_place(q, mode)) {
+        float *qn = reinterpret_cast<float *>(ws + pl.off_qn);
+        hipLaunchKernelGGL(ms_prepare_queries_kernel, dim3((pl.nq_pad + 3) / 4), dim3(256), 0, st, q, nq, pl.nq_pad,
+                           mode == MS_MODE_COSINE_RAW ? 1 : 0, 1e-8f, qn);
+        MS_LAUNCH_CHECK("ms_prepare_queries_kernel");
+    }
     if (mode == MS_MODE_COSINE_RAW && inv_norm == nullptr && n > 0) {
         float *inv_ws = reinterpret_cast<float *>(ws + pl.off_inv);
         const int64_t blocks = (n + 3) / 4;
@@ -512,7 +519,7 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
                            db, n, 1e-8f, inv_ws);
         MS_LAUNCH_CHECK("ms_row_inv_norms_kernel");
     }
-    fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, sp);
+    fill_scan_params(pl, db, n, q, nq, inv_norm, lengths, qlen, mincov, ws, mode, sp);
     return MS_OK;
 }
 
@@ -585,7 +592,7 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     char *ws = (char *)workspace;
     ScanParams sp;
     // same parameters as ms_ip_topk_prepare left in the workspace (queries, inverse norms, lower bound)
-    fill_scan_params(pl, db, n, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
+    fill_scan_params(pl, db, n, q, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
     if (pl.prepass_tiles > 0) sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
     return launch_scan(pl, sp, (hipStream_t)stream);
 }

@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--nq", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exercise-exchange", action="store_true",
+                    help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
     ap.add_argument("--streams", type=int, default=1,
                     help="query batches in flight: consecutive steps alternate over this many HIP streams, each with its own "
                          "workspace (batch i+1's short kernels fill the tail of batch i's scan)")
@@ -114,7 +116,7 @@ def main():
             if events is not None:
                 events[1].record()
             ops.ip_topk_finish(n_local, nq, k, ws, ex.out_s, ex.out_i, row_offset=lo)
-            if world > 1:
+            if world > 1 or args.exercise_exchange:
                 ex.exchange()                                               # ONE RCCL all-gather of 12*nq*k bytes per rank
                 return ex.merge()                                           # merge of the S blocks in place
             return ex.out_s, ex.out_i

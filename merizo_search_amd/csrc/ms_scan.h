@@ -565,10 +565,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 
     if (wave == 4) {
         // ---------------- loader ----------------
-#ifdef MS_ABL_NOFLAG
-        if (lane == 0) for (int i = 0; i < LDR_R; ++i) full[i] = 0x7FFFFFFFu;
-        return;
-#endif
         // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs
         // back to back, so it is written to need as few instructions as possible: raised priority,
         // and every LDS-DMA piece is one s_mov m0 + one global_load_lds with an SGPR base and a
@@ -756,9 +752,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
     auto stage = [&](int t, f32x16 &prev, f32x16 &out) {       // prev (raw scores of tile t-1) is scaled in place
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
-#ifndef MS_ABL_NOFLAG
         if (lane == 0) consumed[wave] = (uint32_t)(t + 1);
-#endif
         // fragment f of this lane's row sits at float4 column (16 h + f) ^ (r & 15) of the slot:
         // byte address = (slot + frag_a0) ^ (16 f) -- ONE address register and one v_xor per read
         // instead of 16 precomputed lane offsets (the slot base has no bits below 2^14)
@@ -777,23 +771,16 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-#ifndef MS_ABL_NOFILTER
             if (tt >= 2 && tt < 6) {
                 if (UB) filter_group(prev, t - 1, tt - 2, false, sc, m);
                 else scale_group(prev, t - 1, tt - 2, mx);
             }
-#else
-            if (tt == 2) { for (int i = 0; i < 16; ++i) { m[i] = 0; sc[i] = 0.0f; asm volatile("" :: "v"(prev[i])); } }
-#endif
-#ifndef MS_ABL_NOFLAG
             if (tt == 4) {      // flag of tile t+1: read issued here, looked at three groups later (asm: hipcc would sink the read to its use)
                 const uint32_t fa = (uint32_t)(uintptr_t)(full + (t + 1) % LDR_R);     // LDS byte address
                 asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(fa) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
             }
-#endif
         }
-#ifndef MS_ABL_NOFLAG
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) : : "memory");
         flag = __builtin_amdgcn_readfirstlane(flag);
@@ -807,7 +794,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #else
         if (t + 1 < ntl && flag < (uint32_t)(t + 2)) wait_tile(t + 1);   // normally long since published
 #endif
-#endif
 #pragma unroll
         for (int tt = 8; tt < 16; ++tt) {
             const f32x4 a = areg[tt];
@@ -815,11 +801,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-#ifndef MS_ABL_NOREFILL
             const int f0 = 2 * (tt - 8);        // fragments of groups already consumed <- tile t+1
             areg[f0] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * f0)));
             areg[f0 + 1] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * (f0 + 1))));
-#endif
         }
         out = acc;
         if (UB) {

@@ -69,11 +69,18 @@ def main():
     from merizo_search_amd.foldclass.sharded import PackedExchange, allgather_results, shard_bounds
 
     _lib.require_gpu()                                   # fails loudly without the HIP library / a GPU
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # self-test hooks (one-GPU boxes): MS_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
+    # MS_BENCH_BACKEND=gloo swaps the collective backend, so that the multi-rank logic can be run end to end
+    dev_index = 0 if os.environ.get("MS_BENCH_SAME_DEVICE") == "1" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("MS_BENCH_BACKEND", "nccl")             # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     n_total, nq, k = args.rows, args.nq, args.k
     lo, hi = shard_bounds(n_total, world, rank)

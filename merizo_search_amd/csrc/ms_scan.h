@@ -311,6 +311,31 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             }
         };
 
+        // In the pipeline (full tiles, no upper bound, not the sample pass) the filter is one compare per
+        // TILE: final scores of group g -> sc and the lane's running maximum; the per-score ballots are
+        // taken only when some lane's maximum passes its threshold.
+        auto scale_max_group = [&](const f32x16 &acc, int64_t sub_row0, int g, float (&sc)[16], float &mx) {
+            f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (AUX) {
+                const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
+                const f32x4 *ax = reinterpret_cast<const f32x4 *>(aux0 + tix * 64 + 8 * g + 4 * h);
+                inv4 = ax[0];
+                len4 = ax[8];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float s = acc[4 * g + j];
+                if (AUX) {
+                    float sv = s * inv4[j];
+                    const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;
+                    sv = sv * mk;
+                    s = (sub_row0 >= row_begin) ? sv : -INFINITY;
+                }
+                sc[4 * g + j] = s;
+            }
+            mx = fmaxf(mx, fmaxf(fmaxf(sc[4 * g], sc[4 * g + 1]), fmaxf(sc[4 * g + 2], sc[4 * g + 3])));
+        };
+
         // one pipeline stage: MFMA chain of tile t from `areg`; each fragment register is
         // refilled with tile t+1 right after its 4 MFMAs were issued; the filter of tile t-1
         // (scores in `prev`) is spread over the first MFMA gaps; its insertion steps follow.
@@ -326,8 +351,10 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             const int tnext = (t + 2 < nfull) ? t + 2 : nfull - 1;
             const char *dma_src = reinterpret_cast<const char *>(p.db) + (row_begin + (int64_t)tnext * 32) * 512;
             f32x4 *dma_dst = slot0 + (t & 1) * 1024;
+            constexpr bool FAST = !UB && !MAXONLY;
             float sc[16];
             uint64_t m[16];
+            float mx = -INFINITY;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
@@ -349,13 +376,24 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                     areg[f0] = src[(16 * h + f0) ^ (r & 15)];
                     areg[f0 + 1] = src[(16 * h + f0 + 1) ^ (r & 15)];
                 }
-                if (tt >= 2 && tt < 6) filter_group(prev, prev_row0, tt - 2, false, sc, m);
+                if (tt >= 2 && tt < 6) {
+                    if (FAST) scale_max_group(prev, prev_row0, tt - 2, sc, mx);
+                    else filter_group(prev, prev_row0, tt - 2, false, sc, m);
+                }
             }
             out = acc;
-            uint64_t any = 0;
+            if (FAST) {
+                if (__ballot(mx > st.tau) != 0) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+                    for (int i = 0; i < 16; ++i) m[i] = __ballot(sc[i] > st.tau);
+                    ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+                }
+            } else {
+                uint64_t any = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) any |= m[i];
+                if (any != 0) ms_tile_insert<KL>(st, sc, m, prev_row0, r, h);
+            }
         };
 
         f32x16 last;   // scores of the tile whose candidates are not inserted yet

@@ -177,7 +177,7 @@ def main():
         else:
             roof = {"bound": "hbm", "achieved": bytes_ / t_scan / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": hbm_frac, "traffic": None}
-        roof.update({"kernel": "ms_scan_loader_kernel" if nq > 64 else "ms_scan_kernel", "kernel_ms": scan_ms,
+        roof.update({"kernel": "ms_scan_loader_kernel" if (nq > 64 and k <= 20) else "ms_scan_kernel", "kernel_ms": scan_ms,
                      "mfma_frac": mfma_frac, "hbm_frac": hbm_frac, "rows_per_launch": scan_rows,
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
         # HBM traffic of one launch of that kernel from the committed PMC passes of this same command

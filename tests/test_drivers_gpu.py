@@ -110,3 +110,23 @@ def test_cli_search_and_easy_search_end_to_end(golden_dir, tmp_path):
     assert rows[0][1] == "71-189" and rows[0][4] == "0"
     r = run("search", m0, str(tmp_path / "db"), str(tmp_path / "out"), str(tmp_path / "tmp"), "-d", "cpu")
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)          # no CPU fallback
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: a plain-C program (tests/c_abi/abi_smoke.c, no Python or torch in the
+    process) normalises, searches two shards, merges and checks against its own brute force."""
+    import shutil
+    import subprocess
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None or not os.path.isdir("/opt/rocm/include"):
+        pytest.skip("needs gcc and the ROCm headers")
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(repo, "merizo_search_amd")
+    build = subprocess.run(["gcc", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(repo, "include"),
+                            os.path.join(repo, "tests", "c_abi", "abi_smoke.c"), "-L" + libdir, "-lmerizo_search_amd",
+                            "-L/opt/rocm/lib", "-lamdhip64", "-lm", "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    env = dict(os.environ, LD_LIBRARY_PATH=libdir + ":/opt/rocm/lib:" + os.environ.get("LD_LIBRARY_PATH", ""))
+    run = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "abi_smoke ok" in run.stdout

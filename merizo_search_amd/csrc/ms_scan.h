@@ -568,7 +568,7 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int KL, bool AUX, bool UB>
+template <int KL, bool AUX>
 __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -720,9 +720,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
     const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;      // no lengths: +inf >= x * 0
     const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
-    float ubs = INFINITY;
-    uint32_t ubi = 0;
-    if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
 
     auto wait_tile = [&](int t) {          // until the loader has published tile t
         const uint32_t need = (uint32_t)(t + 1);
@@ -752,10 +749,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             sc[4 * g + j] = s;
             bool pass = s > st.tau;
             if (check_rows) pass = pass && (rbase + j < row_end);
-            if (UB) {
-                const uint32_t lrow = (uint32_t)(rbase + j);
-                pass = pass && ((s < ubs) || (s == ubs && lrow > ubi));
-            }
             m[4 * g + j] = __ballot(pass);
         }
     };
@@ -809,10 +802,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-            if (tt >= 2 && tt < 6) {
-                if (UB) filter_group(prev, t - 1, tt - 2, false, sc, m);
-                else scale_group(prev, t - 1, tt - 2, mx);
-            }
+            if (tt >= 2 && tt < 6) scale_group(prev, t - 1, tt - 2, mx);
             if (tt == 4) {      // flag of tile t+1: read issued here, looked at three groups later (asm: hipcc would sink the read to its use)
                 const uint32_t fa = (uint32_t)(uintptr_t)(full + (t + 1) % LDR_R);     // LDS byte address
                 asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(fa) : "memory");
@@ -844,12 +834,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             areg[f0 + 1] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * (f0 + 1))));
         }
         out = acc;
-        if (UB) {
-            uint64_t any = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
-        } else if (__ballot(mx > st.tau) != 0) {
+        if (__ballot(mx > st.tau) != 0) {
 #ifdef MS_STAMP
             const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -952,9 +937,9 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
     }
     if constexpr (KL <= 10 && !UB) {    // loader-wave form: short lists only (its compute waves must fit 256 registers)
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, UB>),
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
-            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
             MS_LAUNCH_CHECK("ms_scan_loader_kernel");
             return MS_OK;
         }

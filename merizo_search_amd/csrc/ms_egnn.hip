@@ -39,6 +39,7 @@ constexpr int NIN = 384;
 constexpr int NHID = 256;
 constexpr int TILE_E = 128;      // edges per workgroup tile (4 waves x 32 rows)
 constexpr int NODES_PB = 16;     // nodes per workgroup in the node-level kernels
+constexpr int PROJ_NODES = 64;   // nodes per workgroup of the projection kernel
 constexpr int LAYER_FLOATS = 396165;
 
 // canonical blob offsets (state_dict order, see include/merizo_search_amd.h)
@@ -183,32 +184,42 @@ __global__ __launch_bounds__(256) void ms_egnn_init_nodes_kernel(const int32_t *
 // ApT4[kq][g] (float4) = b1[4kq..] + sum_k h[g][k] W1[4kq..][k];  BpT4 likewise with W1[:,128+k], no bias.
 __global__ __launch_bounds__(256) void ms_egnn_proj_kernel(const float *__restrict__ prep, const float *__restrict__ h,
                                                           int total, f32x4 *__restrict__ ApT4, f32x4 *__restrict__ BpT4) {
-    __shared__ float hs[NODES_PB][DIM + 1];
-    const int g0 = blockIdx.x * NODES_PB;
+    // 64 nodes per workgroup; a thread owns one 4-channel quad (looping over the 130 quads in steps
+    // of 16) for 4 nodes, so every pair of weight float4 it loads feeds 32 FMAs.  Per output the k
+    // order of the fmaf chain is unchanged.
+    __shared__ float hs[PROJ_NODES][DIM + 1];
+    const int g0 = blockIdx.x * PROJ_NODES;
     const int tid = threadIdx.x;
-    for (int e = tid; e < NODES_PB * DIM; e += 256) {
+    for (int e = tid; e < PROJ_NODES * DIM; e += 256) {
         const int n = e >> 7, k = e & 127;
         hs[n][k] = (g0 + n < total) ? h[(size_t)(g0 + n) * DIM + k] : 0.0f;
     }
     __syncthreads();
     const int n = tid & 15, cq0 = tid >> 4;
-    const bool valid = g0 + n < total;
     const f32x4 *w1a = reinterpret_cast<const f32x4 *>(prep + P_W1AT);
     const f32x4 *w1b = reinterpret_cast<const f32x4 *>(prep + P_W1BT);
     const f32x4 *b1 = reinterpret_cast<const f32x4 *>(prep + P_B1);
     for (int cq = cq0; cq < KQ; cq += 16) {
-        f32x4 a = b1[cq];
-        f32x4 b = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll 8
+        f32x4 a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { a[j] = b1[cq]; b[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+#pragma unroll 4
         for (int k = 0; k < DIM; ++k) {
-            const float x = hs[n][k];
             const f32x4 wa = w1a[k * KQ + cq], wb = w1b[k * KQ + cq];
-            a.x = fmaf(x, wa.x, a.x); a.y = fmaf(x, wa.y, a.y); a.z = fmaf(x, wa.z, a.z); a.w = fmaf(x, wa.w, a.w);
-            b.x = fmaf(x, wb.x, b.x); b.y = fmaf(x, wb.y, b.y); b.z = fmaf(x, wb.z, b.z); b.w = fmaf(x, wb.w, b.w);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float x = hs[n + 16 * j][k];
+                a[j].x = fmaf(x, wa.x, a[j].x); a[j].y = fmaf(x, wa.y, a[j].y); a[j].z = fmaf(x, wa.z, a[j].z); a[j].w = fmaf(x, wa.w, a[j].w);
+                b[j].x = fmaf(x, wb.x, b[j].x); b[j].y = fmaf(x, wb.y, b[j].y); b[j].z = fmaf(x, wb.z, b[j].z); b[j].w = fmaf(x, wb.w, b[j].w);
+            }
         }
-        if (valid) {
-            ApT4[(size_t)cq * total + g0 + n] = a;
-            BpT4[(size_t)cq * total + g0 + n] = b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int node = g0 + n + 16 * j;
+            if (node < total) {
+                ApT4[(size_t)cq * total + node] = a[j];
+                BpT4[(size_t)cq * total + node] = b[j];
+            }
         }
     }
 }
@@ -576,7 +587,8 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
     float *hin = h0, *hout = h1;
     for (int layer = 0; layer < 2; ++layer) {
         const float *lp = prep + (size_t)layer * P_LAYER;
-        hipLaunchKernelGGL(ms_egnn_proj_kernel, dim3(node_blocks), dim3(256), 0, st, lp, hin, (int)total, ap, bp);
+        hipLaunchKernelGGL(ms_egnn_proj_kernel, dim3((unsigned)((total + PROJ_NODES - 1) / PROJ_NODES)), dim3(256), 0, st, lp, hin,
+                           (int)total, ap, bp);
         MS_LAUNCH_CHECK("ms_egnn_proj_kernel");
         EdgeParams ep;
         ep.prep = lp; ep.coords = coords; ep.offsets = offsets; ep.tile_pre = tile_pre; ep.rec_pre = rec_pre;

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 #define EST(acc)
 #endif
     for (int s = 0; s < NSTAGE; ++s) {
+        // VALU phases run at raised priority: the other workgroup's wave on this SIMD is issuing MFMAs back
+        // to back and would otherwise keep most of the issue slots, although an MFMA needs 8 of every 64
+        __builtin_amdgcn_s_setprio(3);
         // H = SiLU(Ap_i + Bp_j + w_c * d2), written straight into A-fragment order
 #pragma unroll
         for (int g = 0; g < STAGE_G; ++g) {
@@ -314,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 #pragma unroll
         for (int it = 0; it < 2 * STAGE_G; ++it) Wl[it * 256 + tid] = pw[it];
         EST(tH)
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         EST(tB1)
         if (s + 1 < NSTAGE) issue_loads(s + 1);
@@ -337,6 +341,7 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
     const unsigned long long t_loop_end = tc;
 #endif
 
+    __builtin_amdgcn_s_setprio(3);
     // ---- epilogue.  acc[nt][r]: edge row (r&3) + 8(r>>2) + 4(lane>>5) of this wave's 32 rows,
     //      channel 32 nt + (lane & 31).
     const int c = lane & 31, hh = lane >> 5;

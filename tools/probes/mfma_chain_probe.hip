@@ -96,6 +96,27 @@ __global__ __launch_bounds__(256, 1) void probe16(const float *in, float *out, u
     if (lane == 0) { stamps[(blockIdx.x * 4 + wave) * 2] = c1 - c0; stamps[(blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0; }
 }
 
+// the single chain with the accumulator forced into AGPRs (inline asm, "+a" constraint)
+__global__ __launch_bounds__(256, 1) void probe_agpr(const float *in, float *out, unsigned long long *stamps, int iters) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float q[64], a[64];
+    for (int i = 0; i < 64; ++i) { q[i] = in[lane * 64 + i]; a[i] = in[(lane * 37 + i) & 4095]; }
+    f32x16 acc, sum;
+    for (int i = 0; i < 16; ++i) sum[i] = 0;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int it = 0; it < iters; ++it) {
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+#pragma unroll
+        for (int s = 0; s < 64; ++s) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a[s]), "v"(q[s]));
+        for (int i = 0; i < 16; ++i) sum[i] = fmaxf(sum[i], acc[i]);
+    }
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float sres = 0;
+    for (int i = 0; i < 16; ++i) sres += sum[i];
+    out[blockIdx.x * 256 + tid] = sres;
+    if (lane == 0) { stamps[(blockIdx.x * 4 + wave) * 2] = c1 - c0; stamps[(blockIdx.x * 4 + wave) * 2 + 1] = r1 - r0; }
+}
+
 template <int MODE>
 void run(const char *name, float *in, float *out, unsigned long long *st, int blocks, int iters) {
     for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(probe<MODE>, dim3(blocks), dim3(256), 0, 0, in, out, st, iters);
@@ -126,6 +147,13 @@ int main() {
         hipMemcpy(h.data(), st, blocks * 8 * 8, hipMemcpyDeviceToHost);
         printf("16x16x4, four interleaved accumulators:      cycles per tile (128 MFMA) %.1f (32x32x2: 64 MFMA x the figure above; nominal 4096) | clock %.3f GHz\n",
                (double)h[0] / iters, (double)h[0] / h[1] * 0.1);
+    }
+    {
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(probe_agpr, dim3(blocks), dim3(256), 0, 0, in, out, st, iters);
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h(blocks * 8);
+        hipMemcpy(h.data(), st, blocks * 8 * 8, hipMemcpyDeviceToHost);
+        printf("single chain, accumulator in AGPRs:           cycles/MFMA %.2f | clock %.3f GHz\n", (double)h[0] / (64.0 * iters), (double)h[0] / h[1] * 0.1);
     }
     // sustained rate: ~2 s of back-to-back launches of the pure chain, wall-clocked with events
     {

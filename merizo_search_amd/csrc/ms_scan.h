@@ -540,9 +540,16 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 // consumed.  No barrier: a wave delayed by insertions may trail the others by LDR_R - 1 tiles
 // before the loader has to wait for it.  (The kernel needs <= 256 registers per wave so that
 // the loader can share a SIMD with a compute wave: __launch_bounds__(320, 2).)
-constexpr int LDR_R = 4;        // ring slots (tiles)
-constexpr int LDR_D = 3;        // tiles the loader keeps in flight before publishing the oldest
-constexpr int LDR_AUX = 8;      // aux (row scale / length) ring: a tile's aux data outlives its slot by two stages
+#ifndef MS_LDR_R
+#define MS_LDR_R 8
+#endif
+#ifndef MS_LDR_D
+#define MS_LDR_D 3
+#endif
+constexpr int LDR_R = MS_LDR_R;  // ring slots (tiles); 8 instead of 4 is worth 1.4 % per tile (stamps): fast waves may run further ahead
+constexpr int LDR_D = MS_LDR_D;  // tiles the loader keeps in flight before publishing the oldest
+constexpr int LDR_AUX = 2 * LDR_R;   // aux (row scale / length) ring: a tile's aux data is read up to two stages after its slot was
+                                     // released, while the loader may run LDR_R - 1 tiles ahead of the slowest wave
 constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
 
 // LDS-DMA pieces as inline asm (the loader wave sets M0 itself; nothing else in that wave uses M0):
@@ -565,6 +572,8 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
     else if (N * P == 17) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
     else if (N * P == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
     else if (N * P == 34) asm volatile("s_waitcnt vmcnt(34)" ::: "memory");
+    else if (N * P == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+    else if (N * P == 51) asm volatile("s_waitcnt vmcnt(51)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 

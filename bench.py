@@ -208,11 +208,11 @@ def main():
                      "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
         # HBM traffic of one launch of that kernel from the committed PMC passes of this same command
         # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction applied)
-        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v8.json")
+        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v9.json")
         if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10) and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_c2_pmc_v8.json"
+            roof["traffic_source"] = "profiles/r01_c2_pmc_v9.json"
         line = {
             "metric": "queries/sec (exact 128-d cosine top-k, recall@k vs brute force = %.3f)" % recall,
             "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

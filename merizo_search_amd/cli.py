@@ -7,6 +7,14 @@ chopping as an input (--chopping / --segment_tsv) instead of predicting it.
     python -m merizo_search_amd.cli search  <pdb...> <db_name> <output> <tmp> [-d cuda] [-k 10] ...
     python -m merizo_search_amd.cli createdb <input_dir> <out_db> [-d cuda] [--layout pt|faiss|both]
     python -m merizo_search_amd.cli easy-search <pdb...> <db_name> <output> <tmp> --chopping "71-189,190-290"
+
+Several GPUs of one node: start one process per GPU with torchrun,
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m merizo_search_amd.cli search ...
+
+Every rank then uses GPU LOCAL_RANK (whatever -d says), holds and scans 1/N of the database rows, the
+per-shard top-k lists are exchanged with one RCCL all-gather, and rank 0 writes the output files
+(foldclass/sharded.py; replaces the reference's index_cpu_to_all_gpus, dbsearch.py:228-230).
 """
 from __future__ import annotations
 
@@ -19,6 +27,7 @@ import time
 import uuid
 
 from .foldclass import chopping as chop
+from .foldclass import sharded
 from .foldclass.dbsearch import run_dbsearch
 from .foldclass.makedb import run_createdb
 from .foldclass.results import (EASY_SEARCH_FIELDS, SEARCH_FIELDS, check_for_database, parse_output_format,
@@ -47,10 +56,25 @@ def _add_search_flags(p: argparse.ArgumentParser, default_format: str) -> None:
     p.add_argument("--report_insignificant_hits", action="store_true", default=False)
     p.add_argument("--metadata_json", action="store_true", default=False)
     p.add_argument("--multi_domain_search", action="store_true", default=False,
-                   help="Not available in this build (TM-align-bound CPU post-processing, out of scope).")
+                   help="Search DB for entries that match all query domains (all query structures are treated as single "
+                        "domains coming from one chain).  Needs a TM-align binary ($MERIZO_TMALIGN).")
+    p.add_argument("--multi_domain_mode", type=str, default="exhaustive_tmalign", choices=["exhaustive_tmalign"],
+                   help="If --multi_domain_search is used, specifies the multi-domain search mode. Currently only "
+                        "'exhaustive_tmalign' is supported.")
     p.add_argument("--skip_tmalign", action="store_true", default=False,
                    help="Embedding-only search (automatic when no TM-align binary is found).")
     p.add_argument("--weights", type=str, default=None, help="Path to FINAL_foldclass_model.pt.")
+
+
+def _join_process_group(args) -> None:
+    """Under torchrun (WORLD_SIZE > 1): join the process group before the first GPU call and pin this
+    rank to its GPU; ranks other than 0 log warnings only."""
+    rank, world, device = sharded.init_distributed()
+    if world > 1:
+        args.device = device
+        if rank != 0:
+            logging.getLogger().setLevel(logging.WARNING)
+        logging.info(f"{world} ranks, one GPU each: database rows are sharded, rank 0 writes the results.")
 
 
 def _log_command(mode: str) -> None:
@@ -88,6 +112,8 @@ def _search_and_write(args, inputs, inputs_are_ca, pdb_chain, fields, tmp):
         threads=args.threads, mincos=args.mincos, mintm=args.mintm, mincov=args.mincov, inputs_are_ca=inputs_are_ca,
         pdb_chain=pdb_chain, search_batchsize=args.search_batchsize, search_type=args.search_metric,
         skip_tmalign=skip, weights_path=args.weights)
+    if sharded.rank_world()[0] != 0:
+        return                                            # every rank searched its shard; rank 0 reports
     fields = _embedding_only_format(fields, skip)
     write_search_results(results=results, output_file=search_output, format_list=fields, header=args.output_headers,
                          metadata_json=args.metadata_json)
@@ -114,6 +140,7 @@ def search(argv) -> None:
     p.add_argument("tmp", type=str)
     _add_search_flags(p, SEARCH_FIELDS)
     args = p.parse_args(argv)
+    _join_process_group(args)
     tmp = munge_tmp_with_uuid(args.tmp)
     _log_command("search")
     check_for_database(args.db_name)
@@ -138,6 +165,7 @@ def easy_search(argv) -> None:
                         "(repeat the flag once per input).")
     p.add_argument("--segment_tsv", type=str, default=None, help="A reference `_segment.tsv` to take the choppings from.")
     args = p.parse_args(argv)
+    _join_process_group(args)
     tmp = munge_tmp_with_uuid(args.tmp)
     _log_command("easy-search")
     check_for_database(args.db_name)
@@ -166,7 +194,8 @@ def easy_search(argv) -> None:
         doms = chop.domains_from_chopping(pth, chopping, chain)
         domains.extend(doms)
         seg_rows.append(chop.segment_row(pth, chopping, chain, runtime=time.time() - t1))
-    write_segment_results(results=seg_rows, output_file=args.output + "_segment.tsv", header=args.output_headers)
+    if sharded.rank_world()[0] == 0:
+        write_segment_results(results=seg_rows, output_file=args.output + "_segment.tsv", header=args.output_headers)
     if not domains:
         logging.info("easy-search finished after segmentation: no domains to search.")
         return
@@ -184,6 +213,7 @@ def createdb(argv) -> None:
     p.add_argument("--layout", type=str, default="pt", choices=["pt", "faiss", "both"])
     p.add_argument("--weights", type=str, default=None)
     args = p.parse_args(argv)
+    _join_process_group(args)
     _log_command("createdb")
     t0 = time.time()
     run_createdb(pdb_files=args.input_dir, out_db=args.out_db, device=args.device, layout=args.layout, weights_path=args.weights)
@@ -198,6 +228,7 @@ def main(argv=None) -> None:
               "(segment: out of scope, use the reference)", file=sys.stderr)
         sys.exit(2)
     modes[argv[0]](argv[1:])
+    sharded.finalize_distributed()        # (a rank that fails exits on its own; torchrun then ends the others)
 
 
 if __name__ == "__main__":

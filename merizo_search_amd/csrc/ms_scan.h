@@ -552,17 +552,22 @@ constexpr int LDR_AUX = 2 * LDR_R;   // aux (row scale / length) ring: a tile's 
                                      // released, while the loader may run LDR_R - 1 tiles ahead of the slowest wave
 constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
 
-// LDS-DMA pieces as inline asm (the loader wave sets M0 itself; nothing else in that wave uses M0):
-// 64 lanes x 16 B (or 4 B) from global memory to LDS bytes lds_addr + lane * size.
+// LDS-DMA pieces as inline asm; each statement overwrites M0 and declares it as a clobber:
+// 64 lanes x 16 B (or 4 B) from global memory to LDS bytes lds_addr + lane * size.  M0 is a reserved
+// register for hipcc, which therefore warns about the clobber; the clobber is what makes it re-load M0
+// before any later use of its own (LDS-DMA builtins, v_readlane / movrel with M0), so it stays.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory", "m0");
 }
 __device__ __forceinline__ void ms_glds_v16(uint32_t lds_addr, const void *lane_ptr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
 }
 __device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
 }
+#pragma clang diagnostic pop
 
 template <bool AUX, int N>
 __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N tiles' worth of DMA pieces are in flight

@@ -300,14 +300,19 @@ __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores0,
 namespace {
 
 
+// CU count of HIP's current device (the device the caller's tensors live on: the Python front end
+// makes it current for every call), cached per device ordinal.
 int cu_count_cached() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    constexpr int MAX_DEV = 64;
+    static int cus[MAX_DEV] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+    if (cus[dev] == 0) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+        cus[dev] = c;
     }
-    return cus;
+    return cus[dev];
 }
 
 

@@ -15,6 +15,13 @@ What differs, deliberately (DESIGN.md "host drivers"):
     scan, instead of the reference's per-query Python loop; results are the same lists;
   * database row norms are computed once per database (the reference re-normalises the whole
     database for every query);
+  * a faiss-layout database that fits in HBM is uploaded ONCE as one contiguous tensor and scanned
+    with one launch per query batch; only a database larger than the resident budget is streamed
+    in `search_batchsize` blocks (pinned, double-buffered: engine.device_blocks);
+  * with an initialised torch.distributed process group (cli under torchrun) every rank holds and
+    scans only its `sharded.shard_bounds` rows, one all-gather + merge gives every rank the global
+    top-k, and rank 0 alone assembles hit records (sharded.py; replaces index_cpu_to_all_gpus,
+    dbsearch.py:228-230);
   * TM-align is optional (tmalign.py): with no binary the search is embedding-only;
   * reference defects are not reproduced: a single --pdb_chain with several inputs is applied
     to every input (dbsearch.py:523-524 builds a list of lists; :296 raises IndexError); a
@@ -32,6 +39,7 @@ from typing import List, Optional
 
 import numpy as np
 
+from . import sharded
 from . import tmalign as tm
 from .dbutil import (ascii_conv, coord_conv, db_iterator, db_memmap, read_dbinfo, retrieve_bytes,
                      retrieve_names_by_idx, retrieve_start_end_by_idx)
@@ -75,11 +83,17 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
 
 
 def _to_engine(target_dict: dict, engine) -> None:
-    """Make the `.pt` database resident on the engine's device and cache the row norms."""
+    """Make this rank's rows of the `.pt` database resident on the engine's device and cache the
+    row norms.  'database' / 'lengths' / 'inv_norm' then hold rows [row_lo, row_hi) only."""
     if target_dict.get("_engine") is engine:
         return
-    target_dict["database"] = engine.to_device(target_dict["database"])
-    target_dict["lengths"] = engine.to_device(target_dict["lengths"])
+    rank, world = sharded.rank_world()
+    n = int(target_dict["database"].shape[0])
+    lo, hi = sharded.shard_bounds(n, world, rank)
+    target_dict["n_rows"] = n
+    target_dict["row_lo"], target_dict["row_hi"] = lo, hi
+    target_dict["database"] = engine.to_device(target_dict["database"][lo:hi])
+    target_dict["lengths"] = engine.to_device(target_dict["lengths"][lo:hi])
     target_dict["inv_norm"] = engine.row_inv_norms(target_dict["database"], 1e-8)
     target_dict["_engine"] = engine
 
@@ -98,25 +112,27 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
     seqs = query_dict["seq"]
     single = isinstance(seqs, str)
     qlen = np.asarray([len(seqs)] if single else [len(s) for s in seqs], dtype=np.float32)
-    n = target_dict["database"].shape[0]
-    if topk > n:
+    if topk > target_dict["n_rows"]:
         raise RuntimeError("selected index k out of range")
     q = engine.to_device(emb).reshape(-1, 128)
     scores, idx = engine.cosine_topk(target_dict["database"], q, int(topk), inv_norm=target_dict["inv_norm"],
-                                     lengths=target_dict["lengths"], qlen=engine.to_device(qlen), mincov=float(mincov))
+                                     lengths=target_dict["lengths"], qlen=engine.to_device(qlen), mincov=float(mincov),
+                                     row_offset=target_dict["row_lo"])
+    scores, idx = sharded.exchange_and_merge(scores, idx, engine)        # no-op on one rank
     if single:
         return {"scores": scores[0], "indices": idx[0]}
     return {"scores": scores, "indices": idx}
 
 
-def knn_exact(xq, db_blocks, k: int, engine, log=logger):
+def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True):
     """Exact max-inner-product kNN over a database delivered block by block (knn_exact_faiss,
     dbsearch.py:213-248): per block IndexFlat.add/search -> `I += i0` -> ResultHeap merge.
 
-    xq: [nq,d] (already normalised); db_blocks: iterable of float32 [b,d] arrays (memmap slices
-    or device tensors).  Returns (D float32 [nq,k], I int64 [nq,k]) as numpy arrays, best first;
-    missing entries are (-inf, -1) like faiss.  Each block is uploaded once and scanned on the
-    GPU; the running result is merged with ms_topk_merge.
+    xq: [nq,d] (already normalised); db_blocks: iterable of float32 [b,d] blocks -- host arrays
+    (memmap slices: streamed through engine.device_blocks, the copy of block b+1 overlapping the
+    scan of block b) or device tensors (scanned in place; a resident database is ONE such block).
+    Rows are numbered from `row_offset`.  Returns (D float32 [nq,k], I int64 [nq,k]), best first,
+    as numpy arrays (device tensors with to_host=False); missing entries are (-inf, -1) like faiss.
     """
     import time
 
@@ -124,24 +140,28 @@ def knn_exact(xq, db_blocks, k: int, engine, log=logger):
     q = engine.to_device(xq)
     nq = q.shape[0]
     log.info("knn_exact queries size %s k=%d" % (tuple(q.shape), k))
+    blocks = list(db_blocks) if isinstance(db_blocks, (list, tuple)) else db_blocks
+    on_host = not (isinstance(blocks, list) and all(isinstance(b, engine.torch.Tensor) and b.device == q.device for b in blocks))
     best_s = best_i = None
-    i0 = 0
-    for block in db_blocks:
+    i0 = int(row_offset)
+    for block in (engine.device_blocks(b for b in blocks if b.shape[0] > 0) if on_host else blocks):
         ni = block.shape[0]
         if ni == 0:
             continue
-        dev_block = engine.to_device(np.ascontiguousarray(block) if isinstance(block, np.ndarray) else block)
-        s, i = engine.ip_topk(dev_block, q, k, row_offset=i0)
+        s, i = engine.ip_topk(block, q, k, row_offset=i0)
         if best_s is None:
             best_s, best_i = s, i
         else:
             best_s, best_i = engine.topk_merge(_stack(best_s, s), _stack(best_i, i))
         i0 += ni
-        log.info("%d DB elements, %.3f s" % (i0, time.time() - t0))
+        log.info("%d DB elements, %.3f s" % (i0 - int(row_offset), time.time() - t0))
     if best_s is None:
-        return np.full((nq, k), -np.inf, np.float32), np.full((nq, k), -1, np.int64)
+        best_s = engine.to_device(np.full((nq, k), -np.inf, np.float32))
+        best_i = engine.to_device(np.full((nq, k), -1, np.int64))
+    if not to_host:
+        return best_s, best_i
     D, I = best_s.cpu().numpy(), best_i.cpu().numpy()
-    log.info("kNN time: %.3f s (%d vectors)" % (time.time() - t0, i0))
+    log.info("kNN time: %.3f s (%d vectors)" % (time.time() - t0, i0 - int(row_offset)))
     return D, I
 
 
@@ -301,25 +321,30 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
     logger.info("DB iterator using batchsize of " + str(search_batchsize))
 
     query_dicts = _load_queries(queries, inputs_are_ca, _chain_list(pdb_chain, nq))
-    emb = network.embed_many([qd["coords"] for qd in query_dicts])          # one ragged launch
+    emb = sharded.embed_distributed(network, [qd["coords"] for qd in query_dicts])   # ragged launches, data-parallel over ranks
     emb = engine.normalize_(emb.clone() if hasattr(emb, "clone") else emb, 1e-12)   # F.normalize (:303-304)
 
-    # the shard cache keeps the matrix resident in HBM across calls on the same database
-    cache = target_dict.setdefault("_resident", {})
-    if cache.get("engine") is engine and cache.get("n") == dbinfo["DB_SIZE"]:
-        blocks = cache["blocks"]
+    # this rank's rows of the matrix: [lo, hi) of DB_SIZE (all of them on one rank)
+    rank, world = sharded.rank_world()
+    lo, hi = sharded.shard_bounds(int(dbinfo["DB_SIZE"]), world, rank)
+    shard = _resident_shard(target_dict, engine, dbmm, lo, hi, nq, int(topk))
+    if shard is not None:
+        Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False)          # ONE scan launch
     else:
-        blocks = [engine.to_device(np.ascontiguousarray(b)) for b in db_iterator(dbmm, int(search_batchsize))] \
-            if dbinfo["DB_SIZE"] * dbinfo["DB_DIM"] * 4 <= _resident_budget(engine) else None
-        if blocks is not None:
-            cache.update(engine=engine, n=dbinfo["DB_SIZE"], blocks=blocks)
-    D, I = knn_exact(emb, blocks if blocks is not None else db_iterator(dbmm, int(search_batchsize)), int(topk), engine)
+        logger.info("database shard of %d rows exceeds the resident budget: streaming blocks of %d rows"
+                    % (hi - lo, int(search_batchsize)))
+        Ds, Is = knn_exact(emb, db_iterator(dbmm[lo:hi], int(search_batchsize)), int(topk), engine, row_offset=lo,
+                           to_host=False)
+    Ds, Is = sharded.exchange_and_merge(Ds, Is, engine)                   # all-gather + merge; no-op on one rank
+    D, I = Ds.cpu().numpy(), Is.cpu().numpy()
+    results = [dict() for _ in range(nq)]
+    all_results = [dict() for _ in range(nq)]
+    if rank != 0:
+        return results, all_results                                       # rank 0 assembles the hit records
 
     keep = np.where((D >= mincos) & (I >= 0))                  # row-major: grouped by query, rank order
     hit_indices, hit_scores, query_indices = I[keep], D[keep], keep[0]
     n_hits = len(hit_indices)
-    results = [dict() for _ in range(nq)]
-    all_results = [dict() for _ in range(nq)]
     if n_hits == 0:
         return results, all_results
 
@@ -367,13 +392,17 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
     return results, all_results
 
 
-def _resident_budget(engine) -> int:
-    """Bytes of HBM a database may occupy resident (half of what is free now)."""
-    try:
-        free, _total = engine.torch.cuda.mem_get_info(engine.device)
-        return int(free * 0.5)
-    except Exception:
-        return 1 << 62
+def _resident_shard(target_dict: dict, engine, dbmm, lo: int, hi: int, nq: int, k: int):
+    """Rows [lo,hi) of the matrix as one device tensor, kept in `target_dict` across calls on the same
+    database; None when they do not fit the engine's resident budget (-> streaming)."""
+    cache = target_dict.setdefault("_resident", {})
+    if cache.get("engine") is engine and cache.get("span") == (lo, hi):
+        return cache["shard"]
+    cache.clear()
+    if (hi - lo) * dbmm.shape[1] * 4 > engine.resident_budget(nq, k):
+        return None
+    cache.update(engine=engine, span=(lo, hi), shard=engine.upload_rows(dbmm, lo, hi))
+    return cache["shard"]
 
 
 # ------------------------------------------------------------------ dispatcher ---------
@@ -406,11 +435,13 @@ def run_dbsearch(inputs, db_name: str, tmp: str, device, topk: int, fastmode: bo
                               pdb_chain=pdb_chain, skip_tmalign=skip_tmalign)
 
     query_dicts = _load_queries(inputs, inputs_are_ca, _chain_list(pdb_chain, len(inputs)))
-    emb = network.embed_many([qd["coords"] for qd in query_dicts])          # one ragged launch for all inputs
+    emb = sharded.embed_distributed(network, [qd["coords"] for qd in query_dicts])   # ragged launches, data-parallel over ranks
     batch = {"seq": [qd["seq"] for qd in query_dicts], "embedding": emb}
-    top = search_query_against_db(batch, target_db, mincov, topk, engine=network.engine)   # one batched scan
+    top = search_query_against_db(batch, target_db, mincov, topk, engine=network.engine)   # one batched scan (+ exchange)
     top_s, top_i = top["scores"].cpu().numpy(), top["indices"].cpu().numpy()
     search_results, all_search_results = [], []
+    if sharded.rank_world()[0] != 0:
+        return [dict() for _ in query_dicts], [dict() for _ in query_dicts]      # rank 0 assembles the hit records
     for row, qd in enumerate(query_dicts):
         res, all_res = dbsearch(query=qd, target_dict=target_db, tmp=tmp, network=network, topk=topk, mincov=mincov,
                                 mincos=mincos, mintm=mintm, fastmode=fastmode, device=device, inputs_are_ca=True,

@@ -11,9 +11,13 @@ Engine interface (tensors are torch tensors on the engine's device):
     to_device(numpy array)                                  -> tensor
     normalize_(x, eps)                                      -> x, rows L2-normalised in place
     row_inv_norms(db, eps)                                  -> float32 [n]
-    cosine_topk(db, q, k, inv_norm, lengths, qlen, mincov)  -> (scores [nq,k], idx int64 [nq,k])
+    cosine_topk(db, q, k, inv_norm, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
     ip_topk(db, q, k, row_offset)                           -> (scores [nq,k], idx int64 [nq,k])
     topk_merge(scores [S,nq,k], idx [S,nq,k])               -> (scores [nq,k], idx [nq,k])
+    merge_gathered(PackedExchange)                          -> (scores [nq,k], idx [nq,k])  multi-rank merge
+    upload_rows(matrix, lo, hi)                             -> rows [lo,hi) of a host matrix as ONE device tensor
+    device_blocks(blocks)                                   -> iterator of device tensors (out-of-core streaming)
+    resident_budget(nq, k)                                  -> bytes a resident matrix may occupy
 """
 from __future__ import annotations
 
@@ -88,12 +92,102 @@ class HipEngine:
     def row_inv_norms(self, db, eps: float = 1e-8):
         return self._ops.row_inv_norms(db, eps)
 
-    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov: float = 0.0):
+    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov: float = 0.0, row_offset: int = 0):
         return self._ops.ip_topk(db, q, k, mode=self._ops.MODE_COSINE_RAW, inv_norm=inv_norm, lengths=lengths,
-                                 qlen=qlen, mincov=mincov, workspace=self._ws)
+                                 qlen=qlen, mincov=mincov, row_offset=row_offset, workspace=self._ws)
 
     def ip_topk(self, db, q, k, row_offset: int = 0):
         return self._ops.ip_topk(db, q, k, mode=self._ops.MODE_IP_PRENORM, row_offset=row_offset, workspace=self._ws)
 
     def topk_merge(self, scores, idx):
         return self._ops.topk_merge(scores, idx)
+
+    def merge_gathered(self, exchange):
+        """Global top-k from the all-gathered per-shard blocks, read in place (ms_topk_merge_strided)."""
+        return exchange.merge()
+
+    # -- database residency ----------------------------------------------------------
+    STAGE_ROWS = 1 << 19          # 256 MiB pinned staging buffers
+
+    def resident_budget(self, nq: int = 4096, k: int = 64) -> int:
+        """Bytes of HBM a resident matrix may take: what is free now minus the scan workspace of a
+        (nq, k) batch over it, the pinned-upload staging and a margin for the allocator and the encoder."""
+        free, total = self.torch.cuda.mem_get_info(self.device)
+        margin = (2 << 30) + total // 50
+        per_row_ws = 4 + 8                                  # inverse norms (cosine mode) + slack per row
+        budget = free - margin
+        return max(0, int(budget * 512 / (512 + per_row_ws)))
+
+    def _staging(self, rows: int):
+        bufs = getattr(self, "_pinned", None)
+        if bufs is None or bufs[0].shape[0] < rows:
+            bufs = [self.torch.empty((rows, W.DIM), dtype=self.torch.float32).pin_memory() for _ in range(2)]
+            self._pinned = bufs
+        return bufs
+
+    def upload_rows(self, matrix, lo: int, hi: int):
+        """Rows [lo,hi) of a host float32 [N,128] matrix (np.memmap of `dbfname_IP`, or an array) as ONE
+        contiguous device tensor.  The copy goes through two pinned staging buffers on a side stream:
+        the host reads chunk c+1 from the page cache / disk while chunk c crosses PCIe."""
+        torch = self.torch
+        n = hi - lo
+        out = torch.empty((n, W.DIM), dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        step = min(self.STAGE_ROWS, n)
+        bufs = self._staging(step)
+        side = torch.cuda.Stream(device=self.device)
+        busy = [None, None]
+        for c, r0 in enumerate(range(0, n, step)):
+            r1 = min(n, r0 + step)
+            slot = c & 1
+            if busy[slot] is not None:
+                busy[slot].synchronize()                    # the staging buffer's previous copy has left it
+            np.copyto(bufs[slot][: r1 - r0].numpy(), matrix[lo + r0: lo + r1])
+            with torch.cuda.stream(side):
+                out[r0:r1].copy_(bufs[slot][: r1 - r0], non_blocking=True)
+                busy[slot] = side.record_event()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        side.synchronize()
+        return out
+
+    def device_blocks(self, blocks):
+        """Out-of-core streaming (the reference's db_iterator loop, dbsearch.py:233-243): yields each host
+        block as a device tensor.  Double-buffered: while the consumer's scan of block b runs, block
+        b+1 is read into pinned memory and copied on a side stream; a device buffer is overwritten only
+        after the work the consumer enqueued on it has finished (event recorded when the consumer asks
+        for the next block)."""
+        torch = self.torch
+        side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        pinned, dev, copied, used = [None, None], [None, None], [None, None], [None, None]
+
+        def stage(slot, block):
+            rows = block.shape[0]
+            if isinstance(block, torch.Tensor):
+                block = block.numpy()
+            if pinned[slot] is None or pinned[slot].shape[0] < rows:
+                pinned[slot] = torch.empty((rows, W.DIM), dtype=torch.float32).pin_memory()
+                dev[slot] = torch.empty((rows, W.DIM), dtype=torch.float32, device=self.device)
+            if copied[slot] is not None:
+                copied[slot].synchronize()
+            np.copyto(pinned[slot][:rows].numpy(), block)
+            with torch.cuda.stream(side):
+                if used[slot] is not None:
+                    side.wait_event(used[slot])
+                dev[slot][:rows].copy_(pinned[slot][:rows], non_blocking=True)
+                copied[slot] = side.record_event()
+            return rows
+
+        it = iter(blocks)
+        nxt = next(it, None)
+        slot = 0
+        rows = stage(slot, nxt) if nxt is not None else 0
+        while nxt is not None:
+            main.wait_event(copied[slot])
+            yield dev[slot][:rows]                          # the consumer enqueues its scan of this block ...
+            used[slot] = main.record_event()
+            nxt = next(it, None)
+            if nxt is not None:                             # ... and the next block is read + copied meanwhile
+                slot ^= 1
+                rows = stage(slot, nxt)

@@ -10,10 +10,70 @@ when the process group's backend is "nccl".  Every rank then merges the S sorted
 (ResultHeap.add_result / finalize, dbsearch.py:240-245), so all ranks hold identical results.
 
 One process per GPU (torch.distributed); no collective touches the database itself.
+
+The drivers (dbsearch.py, makedb.py) and the CLI use this module whenever a process group is
+initialised -- `python -m torch.distributed.run --nproc-per-node N -m merizo_search_amd.cli
+search ...` (cli.init_distributed): every rank uploads only its `shard_bounds` rows, the query
+structures are embedded data-parallel (`embed_distributed`, split by sum N^2), and rank 0 alone
+retrieves hit records and writes the TSV files.
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+BACKEND_ENV = "MERIZO_DIST_BACKEND"          # "nccl" (= RCCL, default) | "gloo" (self-tests on a one-GPU box)
+SAME_DEVICE_ENV = "MERIZO_SAME_DEVICE"       # "1": every rank uses cuda:0 (self-tests on a one-GPU box; gloo only)
+
+
+def rank_world(group=None) -> Tuple[int, int]:
+    """(rank, world size) of the initialised process group, (0, 1) without one."""
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def init_distributed() -> Tuple[int, int, Optional[str]]:
+    """Join the process group torchrun describes in the environment (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*).  -> (rank, world, device name of this rank or None when WORLD_SIZE is 1).
+
+    Must run before anything else touches the GPU in this process; nothing is exec'd afterwards.
+    Backend "nccl" is RCCL on ROCm (xGMI between the GPUs of a node)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return 0, 1, None
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        rank = dist.get_rank()
+        local = int(os.environ.get("LOCAL_RANK", rank))
+    else:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    index = 0 if os.environ.get(SAME_DEVICE_ENV) == "1" else local
+    device = torch.device("cuda", index)
+    if torch.cuda.is_available():          # (without a GPU the engine set-up that follows fails loudly)
+        torch.cuda.set_device(device)
+    if not dist.is_initialized():
+        backend = os.environ.get(BACKEND_ENV, "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size(), f"cuda:{index}"
+
+
+def finalize_distributed() -> None:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:
@@ -60,6 +120,69 @@ def allgather_results(scores, idx, group=None):
         dist.all_gather(parts, mine, group=group)
         out = torch.stack(parts)
     return unpack_results(out, world, nq, k)
+
+
+def exchange_and_merge(scores, idx, engine, group=None):
+    """Per-shard results (float32 [nq,k], int64 [nq,k], rows numbered globally) -> the global top-k,
+    identical on every rank: one all-gather of the packed blocks + one merge.  No-op at world size 1.
+    `engine.merge_gathered(exchange)` runs the merge (HIP: ms_topk_merge_strided on the gathered
+    buffer in place)."""
+    _rank, world = rank_world(group)
+    if world == 1:
+        return scores, idx
+    nq, k = scores.shape
+    ex = PackedExchange(nq, k, scores.device, group)
+    ex.out_s.copy_(scores)
+    ex.out_i.copy_(idx)
+    ex.exchange()
+    return engine.merge_gathered(ex)
+
+
+def balance_by_cost(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Deterministic longest-processing-time split of item numbers over `world` ranks (every rank
+    computes the same answer).  Items of a rank are in ascending order."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    load = [0.0] * world
+    mine: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda j: (load[j], j))
+        mine[r].append(i)
+        load[r] += float(costs[i])
+    return [sorted(m) for m in mine]
+
+
+def embed_distributed(network, coords_list: Sequence[np.ndarray], group=None):
+    """Embed structures data-parallel over the ranks (no exchange inside the encoder): rank r embeds
+    its share of the ragged batch, balanced by sum N^2 (the encoder's cost), and ONE all-gather of
+    float32 [max share, 128] blocks gives every rank all embeddings, in input order.  A ragged batch
+    and one-by-one launches are bit-identical (tests/test_egnn_gpu.py), so the split does not change
+    any embedding."""
+    rank, world = rank_world(group)
+    if world == 1 or len(coords_list) < 2:
+        return network.embed_many(coords_list)
+    import torch
+    import torch.distributed as dist
+
+    shares = balance_by_cost([float(np.asarray(c).shape[0]) ** 2 for c in coords_list], world)
+    cap = max(len(s) for s in shares)
+    mine = shares[rank]
+    local = network.embed_many([coords_list[i] for i in mine]) if mine else None
+    device = local.device if local is not None else network.engine.device
+    block = torch.zeros((cap, 128), dtype=torch.float32, device=device)
+    if mine:
+        block[: len(mine)] = local
+    gathered = torch.empty((world, cap, 128), dtype=torch.float32, device=device)
+    if dist.get_backend(group) == "nccl":
+        dist.all_gather_into_tensor(gathered, block, group=group)
+    else:
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block, group=group)
+        gathered.copy_(torch.stack(parts))
+    out = torch.empty((len(coords_list), 128), dtype=torch.float32, device=device)
+    for r, share in enumerate(shares):
+        if share:
+            out[torch.as_tensor(share, device=device)] = gathered[r, : len(share)]
+    return out
 
 
 class PackedExchange:

@@ -10,7 +10,33 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import DIM, MODE_COSINE_RAW, MODE_IP_PRENORM, MerizoHipError, check, current_stream, ptr
+from ._lib import DIM, MODE_COSINE_RAW, MODE_IP_PRENORM, MerizoHipError, check, ptr
+
+
+class _on:
+    """Device scope of one C-ABI call: the library launches on HIP's CURRENT device, so every entry
+    point makes the tensors' device current for the call and hands over THAT device's current
+    stream.  All tensor arguments must live on one device."""
+
+    def __init__(self, *tensors):
+        torch = _lib.require_gpu()
+        devs = {t.device for t in tensors if t is not None}
+        if len(devs) != 1:
+            raise MerizoHipError(f"tensors of one call must share a device, got {sorted(str(d) for d in devs)}")
+        self.device = devs.pop()
+        if self.device.type != "cuda":
+            raise MerizoHipError("expected CUDA/HIP tensors")
+        self._guard = torch.cuda.device(self.device)
+        self.stream = None
+
+    def __enter__(self):
+        import torch
+        self._guard.__enter__()
+        self.stream = torch.cuda.current_stream(self.device).cuda_stream
+        return self
+
+    def __exit__(self, *exc):
+        return self._guard.__exit__(*exc)
 
 
 def _f32_cuda(t, name: str, cols: Optional[int] = None):
@@ -27,7 +53,8 @@ def _f32_cuda(t, name: str, cols: Optional[int] = None):
 def l2_normalize_rows_(x, eps: float = 1e-12):
     """In-place F.normalize(x) (reference dbsearch.py:303-304)."""
     _f32_cuda(x, "x", DIM)
-    check(_lib.load().ms_l2_normalize_rows(ptr(x), x.shape[0], DIM, eps, current_stream()), "ms_l2_normalize_rows")
+    with _on(x) as dev:
+        check(_lib.load().ms_l2_normalize_rows(ptr(x), x.shape[0], DIM, eps, dev.stream), "ms_l2_normalize_rows")
     return x
 
 
@@ -36,7 +63,8 @@ def row_inv_norms(x, eps: float = 1e-8):
     torch = _lib.require_gpu()
     _f32_cuda(x, "x", DIM)
     inv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-    check(_lib.load().ms_row_inv_norms(ptr(x), x.shape[0], DIM, eps, ptr(inv), current_stream()), "ms_row_inv_norms")
+    with _on(x) as dev:
+        check(_lib.load().ms_row_inv_norms(ptr(x), x.shape[0], DIM, eps, ptr(inv), dev.stream), "ms_row_inv_norms")
     return inv
 
 
@@ -49,7 +77,8 @@ class TopKWorkspace:
 
     def get(self, n: int, nq: int, k: int):
         torch = _lib.require_gpu()
-        need = int(_lib.load().ms_ip_topk_workspace_bytes(n, nq, k))
+        with torch.cuda.device(self.device):          # the plan depends on the device's CU count
+            need = int(_lib.load().ms_ip_topk_workspace_bytes(n, nq, k))
         if need == 0:
             raise MerizoHipError(f"ms_ip_topk_workspace_bytes rejected n={n} nq={nq} k={k}")
         if self.buf is None or self.buf.numel() < need:
@@ -72,29 +101,33 @@ def ip_topk(db, q, k: int, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=N
     ws = (workspace or TopKWorkspace(db.device)).get(n, nq, k)
     out_s = torch.empty((nq, k), dtype=torch.float32, device=db.device)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
-    check(_lib.load().ms_ip_topk(ptr(db), n, row_offset, ptr(q), nq, k, mode, ptr(inv_norm), ptr(lengths), ptr(qlen),
-                                 mincov, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), current_stream()), "ms_ip_topk")
+    with _on(db, q, inv_norm, lengths, qlen, ws) as dev:
+        check(_lib.load().ms_ip_topk(ptr(db), n, row_offset, ptr(q), nq, k, mode, ptr(inv_norm), ptr(lengths), ptr(qlen),
+                                     mincov, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk")
     return out_s, out_i
 
 
 def ip_topk_prepare(db, q, k: int, ws, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
                     mincov: float = 0.0):
     """Stage 1 of ip_topk (k <= 64): query preparation + sample pass."""
-    check(_lib.load().ms_ip_topk_prepare(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
-                                         ptr(qlen), mincov, ptr(ws), ws.numel(), current_stream()), "ms_ip_topk_prepare")
+    with _on(db, q, inv_norm, lengths, qlen, ws) as dev:
+        check(_lib.load().ms_ip_topk_prepare(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
+                                             ptr(qlen), mincov, ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prepare")
 
 
 def ip_topk_scan(db, q, k: int, ws, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
                  mincov: float = 0.0):
     """Stage 2 of ip_topk (k <= 64): the one launch of the fused score + top-k scan kernel (bench timing)."""
-    check(_lib.load().ms_ip_topk_scan(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
-                                      ptr(qlen), mincov, ptr(ws), ws.numel(), current_stream()), "ms_ip_topk_scan")
+    with _on(db, q, inv_norm, lengths, qlen, ws) as dev:
+        check(_lib.load().ms_ip_topk_scan(ptr(db), db.shape[0], ptr(q), q.shape[0], k, mode, ptr(inv_norm), ptr(lengths),
+                                          ptr(qlen), mincov, ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_scan")
 
 
 def ip_topk_finish(n: int, nq: int, k: int, ws, out_s, out_i, row_offset: int = 0):
     """Stage 3 of ip_topk (k <= 64): merge the per-stream lists into the outputs."""
-    check(_lib.load().ms_ip_topk_finish(n, row_offset, nq, k, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(),
-                                        current_stream()), "ms_ip_topk_finish")
+    with _on(ws, out_s, out_i) as dev:
+        check(_lib.load().ms_ip_topk_finish(n, row_offset, nq, k, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(),
+                                            dev.stream), "ms_ip_topk_finish")
 
 
 def topk_merge(scores, idx):
@@ -109,8 +142,9 @@ def topk_merge(scores, idx):
     S, nq, k = scores.shape
     out_s = torch.empty((nq, k), dtype=torch.float32, device=scores.device)
     out_i = torch.empty((nq, k), dtype=torch.int64, device=scores.device)
-    check(_lib.load().ms_topk_merge(ptr(scores), ptr(idx), S, nq, k, ptr(out_s), ptr(out_i), current_stream()),
-          "ms_topk_merge")
+    with _on(scores, idx) as dev:
+        check(_lib.load().ms_topk_merge(ptr(scores), ptr(idx), S, nq, k, ptr(out_s), ptr(out_i), dev.stream),
+              "ms_topk_merge")
     return out_s, out_i
 
 
@@ -124,8 +158,9 @@ def topk_merge_packed(gathered, S: int, nq: int, k: int, idx_offset: int, out_s,
     if stride * S != gathered.numel() or stride < idx_offset + 8 * nq * k:
         raise MerizoHipError("topk_merge_packed: buffer size does not match S blocks of nq*k results")
     base = gathered.data_ptr()
-    check(_lib.load().ms_topk_merge_strided(base, base + idx_offset, stride, stride, S, nq, k, ptr(out_s), ptr(out_i),
-                                            current_stream()), "ms_topk_merge_strided")
+    with _on(gathered, out_s, out_i) as dev:
+        check(_lib.load().ms_topk_merge_strided(base, base + idx_offset, stride, stride, S, nq, k, ptr(out_s), ptr(out_i),
+                                                dev.stream), "ms_topk_merge_strided")
     return out_s, out_i
 
 
@@ -150,9 +185,9 @@ class EgnnEncoder:
             w_dev = torch.from_numpy(weights).to(self.device)
             self.pe = torch.from_numpy(pe).to(self.device)
             self.prepared = torch.empty(int(lib.ms_egnn_prepared_bytes()), dtype=torch.uint8, device=self.device)
-            check(lib.ms_egnn_prepare_weights(ptr(w_dev), ptr(self.prepared), current_stream()),
-                  "ms_egnn_prepare_weights")
-            torch.cuda.current_stream().synchronize()
+            check(lib.ms_egnn_prepare_weights(ptr(w_dev), ptr(self.prepared),
+                                              torch.cuda.current_stream(self.device).cuda_stream), "ms_egnn_prepare_weights")
+            torch.cuda.current_stream(self.device).synchronize()
         self.max_len = pe.shape[0]
         self._ws = None
 
@@ -180,7 +215,7 @@ class EgnnEncoder:
             out = torch.empty((nb, DIM), dtype=torch.float32, device=self.device)
             check(lib.ms_egnn_embed(ptr(self.prepared), ptr(self.pe), self.max_len, ptr(coords), ptr(offs_dev),
                                     offsets.ctypes.data, nb, ptr(out), ptr(self._ws), self._ws.numel(),
-                                    current_stream()), "ms_egnn_embed")
+                                    torch.cuda.current_stream(self.device).cuda_stream), "ms_egnn_embed")
             # `offsets` (host) is only read during the call; coords/offs_dev stay alive until the
             # stream has consumed them because torch's caching allocator is stream-ordered.
         return out

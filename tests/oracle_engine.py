@@ -40,9 +40,9 @@ class OracleEngine:
         n = np.sqrt((db.numpy().astype(np.float32) ** 2).sum(1, dtype=np.float32))
         return torch.from_numpy((1.0 / np.maximum(n, eps)).astype(np.float32))
 
-    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov=0.0):
+    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov=0.0, row_offset=0):
         s, i = orc.cosine_topk(db.numpy(), q.numpy(), k, None if lengths is None else lengths.numpy(),
-                               None if qlen is None else qlen.numpy(), mincov)
+                               None if qlen is None else qlen.numpy(), mincov, row_offset=row_offset)
         return torch.from_numpy(s), torch.from_numpy(i)
 
     def ip_topk(self, db, q, k, row_offset=0):
@@ -52,6 +52,20 @@ class OracleEngine:
     def topk_merge(self, scores, idx):
         s, i = orc.topk_merge(scores.numpy(), idx.numpy())
         return torch.from_numpy(s), torch.from_numpy(i)
+
+
+    def merge_gathered(self, exchange):
+        return exchange.merge(merge_fn=self.topk_merge)
+
+    def resident_budget(self, nq=4096, k=64):
+        return getattr(self, "budget", 1 << 62)
+
+    def upload_rows(self, matrix, lo, hi):
+        return torch.from_numpy(np.array(matrix[lo:hi], dtype=np.float32))
+
+    def device_blocks(self, blocks):
+        for b in blocks:
+            yield b if isinstance(b, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(b))
 
 
 def oracle_network(seed=0):

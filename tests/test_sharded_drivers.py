@@ -1,0 +1,186 @@
+"""The product drivers on several ranks: run_dbsearch / the CLI with an initialised process group
+(row-sharded database, one all-gather, merge, rank 0 reports) must reproduce the one-rank run --
+TSV text and score bits.  CPU: gloo + the oracle engine.  GPU: gloo between two ranks that share
+cuda:0 (one-GPU box), the HIP engine and ms_topk_merge_strided behind a real collective; plus RCCL
+itself at world size 1."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+WORKER = os.path.join(REPO, "tests", "dist_worker.py")
+
+
+def _make_case(work, n=3001, nq=7, k=10, batch=500):
+    """faiss-layout + `.pt` databases of n rows with exact duplicates on both sides of the 2-rank shard
+    boundary (ties must resolve to the lower row), queries as CA traces."""
+    from merizo_search_amd.foldclass import dbutil, synthetic as syn
+    os.makedirs(work, exist_ok=True)
+    raw, lengths = syn.raw_database(n, seed=11)
+    raw[5] = raw[n - 3]; raw[n // 2 - 1] = raw[n // 2 + 4]; raw[7] = raw[8]
+    names = ["d%06d" % i for i in range(n)]
+    seqs = ["A" * int(l) for l in lengths]
+    coords = [np.zeros((int(l), 3), np.float32) for l in lengths]
+    norm = raw / np.linalg.norm(raw, axis=1, keepdims=True)
+    dbutil.write_faiss_db(os.path.join(work, "fa"), norm.astype(np.float32), names, seqs, coords,
+                          metadata=['{ "row": %d }' % i for i in range(n)])
+    dbutil.write_pt_db(os.path.join(work, "pt"), raw, ["/x/" + nm + ".pdb" for nm in names], coords, seqs)
+    qn, qc, qs = syn.synthetic_structures(nq, seed=3, min_len=30, max_len=120)
+    np.savez(os.path.join(work, "queries.npz"), coords=np.asarray(qc, dtype=object), seqs=np.asarray(qs), names=np.asarray(qn),
+             k=k, batch=batch)
+
+
+def _run_ranks(work, world, kind):
+    port = str(20000 + (os.getpid() * 7 + world * 131 + (kind == "hip") * 17) % 20000)
+    env = dict(os.environ, OMP_NUM_THREADS="2", MERIZO_ALLOW_SYNTHETIC_WEIGHTS="1")
+    procs = [subprocess.Popen([sys.executable, WORKER, REPO, port, str(r), str(world), kind, work], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"rank {r} ok" in o, o[-3000:]
+
+
+def _compare(work, world):
+    for tag in ("fa", "fa_stream", "pt"):
+        one, many = np.load(os.path.join(work, f"{tag}_w1.npz")), np.load(os.path.join(work, f"{tag}_w{world}.npz"))
+        assert np.array_equal(one["rows"], many["rows"]), tag
+        assert np.array_equal(one["scores"].view(np.uint32), many["scores"].view(np.uint32)), tag
+        assert open(os.path.join(work, f"{tag}_w1.tsv")).read() == open(os.path.join(work, f"{tag}_w{world}.tsv")).read(), tag
+    a, b = np.load(os.path.join(work, "fa_w1.npz")), np.load(os.path.join(work, "fa_stream_w1.npz"))
+    assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["scores"].view(np.uint32), b["scores"].view(np.uint32))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_run_dbsearch_sharded_equals_one_rank_gloo_oracle(world, tmp_path):
+    work = str(tmp_path / "case")
+    _make_case(work)
+    _run_ranks(work, 1, "oracle")
+    _run_ranks(work, world, "oracle")
+    _compare(work, world)
+
+
+_CLI_SHIM = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+from oracle_engine import oracle_network
+from merizo_search_amd import cli
+from merizo_search_amd.foldclass import dbsearch as ds, makedb
+net = oracle_network()
+ds.network_setup = lambda **kw: (net, "cpu")
+makedb.network_setup = lambda **kw: (net, "cpu")
+cli.main(sys.argv[2:])
+'''
+
+
+def _torchrun(nproc, argv, env, port):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + argv
+    return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+
+
+def test_cli_under_torchrun_two_ranks_gloo_oracle(tmp_path):
+    """`torchrun --nproc-per-node 2 ... cli easy-search --multi_domain_search` (engine swapped for the oracle
+    by a shim): createdb embeds data-parallel, search shards the rows, rank 0 writes every file once."""
+    import md_case
+    shim = tmp_path / "shim.py"
+    shim.write_text(_CLI_SHIM)
+    qpdb, dbdir = md_case.write_inputs(tmp_path)
+    env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", MERIZO_TMALIGN=md_case.fake_tmalign(tmp_path), OMP_NUM_THREADS="2")
+    port = 21000 + os.getpid() % 10000
+    r = _torchrun(2, [str(shim), REPO, "createdb", dbdir, str(tmp_path / "db"), "--layout", "both"], env, port)
+    assert r.returncode == 0, r.stderr[-3000:]
+    search = ["easy-search", qpdb, str(tmp_path / "db"), None, str(tmp_path / "tmp"), "-k", "3", "-s", "0.5", "--chopping",
+              md_case.CHOPPING, "--multi_domain_search", "--output_headers"]
+    os.remove(tmp_path / "db.pt")                                       # search the faiss layout
+    for nproc, out in ((2, "two"), (1, "one")):
+        argv = [str(shim), REPO] + [a if a is not None else str(tmp_path / out) for a in search]
+        r = _torchrun(nproc, argv, env, port + 1)
+        assert r.returncode == 0, r.stderr[-3000:]
+        md_case.check_outputs(str(tmp_path / out))
+    for suffix in ("_search.tsv", "_segment.tsv", "_search_multi_dom.tsv"):
+        a, b = open(str(tmp_path / "one") + suffix).read(), open(str(tmp_path / "two") + suffix).read()
+        if suffix == "_segment.tsv":                                    # the runtime column differs
+            a, b = [l.split("\t")[:6] + l.split("\t")[7:] for l in a.splitlines()], [l.split("\t")[:6] + l.split("\t")[7:] for l in b.splitlines()]
+        assert a == b, suffix
+
+
+def test_balance_by_cost_is_a_partition_and_balanced():
+    from merizo_search_amd.foldclass.sharded import balance_by_cost
+    rng = np.random.default_rng(0)
+    costs = (rng.integers(25, 700, size=101) ** 2).tolist()
+    for world in (1, 2, 3, 8):
+        shares = balance_by_cost(costs, world)
+        assert sorted(i for s in shares for i in s) == list(range(101))
+        loads = [sum(costs[i] for i in s) for s in shares]
+        assert max(loads) - min(loads) <= max(costs)
+    assert balance_by_cost([], 4) == [[], [], [], []]
+
+
+# ---------------------------------------------------------------------------- GPU ------
+@pytest.mark.gpu
+def test_run_dbsearch_sharded_equals_one_rank_hip_engine_two_ranks(tmp_path):
+    """Two fresh child ranks on cuda:0 over gloo with the HIP engine: sharded scan -> all-gather ->
+    ms_topk_merge_strided == the one-rank run, bit for bit (resident, streamed, and the `.pt` cosine path)."""
+    work = str(tmp_path / "case")
+    _make_case(work, n=200_003, nq=70, k=10, batch=30_000)
+    _run_ranks(work, 1, "hip")
+    _run_ranks(work, 2, "hip")
+    _compare(work, 2)
+
+
+@pytest.mark.gpu
+def test_cli_under_torchrun_two_ranks_on_one_gpu(tmp_path):
+    """The user-facing form: torchrun -m merizo_search_amd.cli createdb / easy-search --multi_domain_search with
+    2 ranks (both on cuda:0, gloo: MERIZO_SAME_DEVICE / MERIZO_DIST_BACKEND) against the 1-process CLI."""
+    import md_case
+    qpdb, dbdir = md_case.write_inputs(tmp_path)
+    env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", MERIZO_SAME_DEVICE="1", MERIZO_ALLOW_SYNTHETIC_WEIGHTS="1",
+               MERIZO_TMALIGN=md_case.fake_tmalign(tmp_path), PYTHONPATH=REPO)
+    port = 22000 + os.getpid() % 10000
+    r = _torchrun(2, ["-m", "merizo_search_amd.cli", "createdb", dbdir, str(tmp_path / "db"), "--layout", "faiss"], env, port)
+    assert r.returncode == 0, r.stderr[-3000:]
+    search = ["easy-search", qpdb, str(tmp_path / "db"), None, str(tmp_path / "tmp"), "-k", "3", "-s", "0.5", "--chopping",
+              md_case.CHOPPING, "--multi_domain_search", "--multi_domain_mode", "exhaustive_tmalign", "--output_headers"]
+    r = _torchrun(2, ["-m", "merizo_search_amd.cli"] + [a if a is not None else str(tmp_path / "two") for a in search], env, port + 1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([sys.executable, "-m", "merizo_search_amd.cli"] + [a if a is not None else str(tmp_path / "one") for a in search],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for out in ("one", "two"):
+        md_case.check_outputs(str(tmp_path / out))
+    for suffix in ("_search.tsv", "_search_multi_dom.tsv"):
+        assert open(str(tmp_path / "one") + suffix).read() == open(str(tmp_path / "two") + suffix).read(), suffix
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_runs_at_world_size_one(tmp_path):
+    """RCCL itself on the hardware there is: a 1-rank "nccl" group, PackedExchange's all_gather_into_tensor
+    branch and the in-place merge of the gathered block."""
+    script = tmp_path / "rccl1.py"
+    script.write_text(r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+from merizo_search_amd.foldclass.sharded import PackedExchange
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=0, world_size=1, device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+db = syn.device_database(50_000, 0, seed=0, device="cuda:0")
+q = syn.device_database(33, 0, seed=1, device="cuda:0")
+s, i = ops.ip_topk(db, q, 10, row_offset=1000)
+ex = PackedExchange(33, 10, "cuda:0")
+ex.out_s.copy_(s); ex.out_i.copy_(i)
+g = ex.exchange()                       # dist.all_gather_into_tensor over RCCL
+ms, mi = ex.merge()                     # ms_topk_merge_strided on the gathered block
+torch.cuda.synchronize()
+assert torch.equal(ms, s) and torch.equal(mi, i)
+dist.destroy_process_group()
+print("rccl ok")
+''')
+    r = subprocess.run([sys.executable, str(script), REPO, str(23000 + os.getpid() % 10000)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

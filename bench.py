@@ -5,24 +5,34 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Default workload = BASELINE.json configs[1] (C2): brute-force cosine top-10 over a 1M x 128
-float32 synthetic database, batch = 256 queries.  A step is one pass of the hot path over one
-query batch: normalised queries -> fused Q.D^T + top-k scan of the resident shard -> merge of
-the per-chunk lists [-> RCCL all-gather of per-shard top-k + shard merge when N > 1].
-With N > 1 the SAME database is row-sharded over the ranks (strong scaling: total work fixed).
-The database and the queries are resident in HBM before the timed region starts.
-`--rows 365000000 --nq 4096` runs the TED-scale shape (C4).  `--streams 2` keeps two query batches
-in flight on two HIP streams (batch i+1's short kernels fill the tail of batch i's scan: +5 % q/s
-at C2); the default is one, so that the HIP-event duration of the scan launch is that kernel alone.
+N = 1 (default): BASELINE.json configs[1] (C2) -- brute-force cosine top-10 over a 1M x 128 float32
+synthetic database, batch = 256 queries.  A step is one pass of the hot path over one query batch:
+raw query embeddings -> ms_l2_normalize_rows -> sample pass -> fused Q.D^T + top-k scan of the
+resident shard -> merge of the per-stream lists [-> RCCL all-gather of the per-shard top-k + shard
+merge when N > 1].  The database and the raw query embeddings are resident in HBM before the timed
+region starts.
+
+N > 1: the TED shape of BASELINE.json configs[3] (C4), weak scaling -- every rank generates and holds
+45,625,000 rows (23.4 GB; 8 ranks = the 365M-row database), batch = 4096 queries, one all-gather
+of 12*nq*k bytes per rank and one merge per step.  queries/s is then (nearly) constant in N while the
+database grows N-fold; the N = 1 point of that curve is the `c4_shard` entry of the default run.
+`--rows R` overrides either default with R total rows sharded over the ranks (strong scaling).
 
 One JSON line is printed by rank 0 (contract in the task statement), with
-  roofline     for the dominant kernel (ms_scan_loader_kernel; ms_scan_kernel for < 3 query tiles):
-               algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the
-               scan stage, against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else
-               algorithmic bytes (512 B per row) against the 8 TB/s HBM peak; both fractions
-               are always included;
-  cpu_baseline the CPU oracle (oracle/oracle.c, a restatement of the reference's faiss path)
-               timed on this host's cores on a bounded sample of the same workload.
+  roofline      dominant kernel (ms_scan_loader_kernel; ms_scan_kernel below 3 query tiles):
+                algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the scan
+                launch against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic
+                bytes (512 B per row) against the 8 TB/s HBM peak; both fractions always included,
+                plus `step_frac`: the same work over the whole step time (what the user gets);
+  cpu_baseline  the CPU oracle (oracle/oracle.c: AVX2 + OpenMP port of the faiss path) on this host's
+                cores, and under `torch_cpu` the reference's own torch op shapes (oracle/torch_baseline.py)
+                -- per-query cosine_similarity*mask->topk, blockwise-262,144 normalize->Q@D^T->topk->merge,
+                batch=1 EGNN loop; all on bounded samples;
+  hbm_regime    (N = 1) nq = 1 / 8 / 32 over 1M and 45.6M rows: GB/s against the HBM peak;
+  c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
+  embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
+                peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
+`--no-extras` skips the last three, `--no-cpu-baseline` the CPU legs.
 """
 import argparse
 import json
@@ -37,6 +47,224 @@ sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK = 157.3e12     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 HBM_PEAK = 8.0e12            # same guide, "HBM3E peak BW" (spec)
+C4_ROWS_PER_GPU = 45_625_000
+C4_NQ = 4096
+
+
+def scan_kernel_name(nq, k):
+    return "ms_scan_loader_kernel" if (nq > 64 and k <= 20) else "ms_scan_kernel"
+
+
+def roofline(nq, rows, k, scan_ms, step_ms):
+    """Both roofs for one scan launch over `rows` rows; the binding one is `frac`."""
+    flops = 2.0 * 128 * nq * rows
+    bytes_ = 512.0 * rows
+    t = scan_ms * 1e-3
+    mfma_frac, hbm_frac = flops / t / MFMA_F32_PEAK, bytes_ / t / HBM_PEAK
+    if nq >= 39:
+        roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": mfma_frac,
+                "step_frac": flops / (step_ms * 1e-3) / MFMA_F32_PEAK}
+    else:
+        roof = {"bound": "hbm", "achieved": bytes_ / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac,
+                "step_frac": bytes_ / (step_ms * 1e-3) / HBM_PEAK}
+    roof.update({"traffic": None, "kernel": scan_kernel_name(nq, k), "kernel_ms": scan_ms, "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
+                 "rows_per_launch": rows, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
+    return roof
+
+
+class SearchBench:
+    """One shard resident on this rank + a query batch; `step()` is the timed unit."""
+
+    def __init__(self, torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=False):
+        self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
+        self.n_total, self.lo, self.n_local, self.nq, self.k = n_total, lo, hi - lo, nq, k
+        self.exchange = exchange or world > 1
+        # synthetic inputs (SURVEY.md 8d): unit rows ~ N(0,1)/|.| (seed 0, independent of the sharding); raw
+        # queries ~ N(0,1) (seed 1); 3 near-duplicates of every query planted at known global rows
+        self.db = syn.device_database(self.n_local, lo, seed=0, device=dev, normalize=True)
+        g = torch.Generator(device=dev); g.manual_seed(1)
+        self.q_raw = torch.randn((nq, 128), generator=g, device=dev, dtype=torch.float32) * 3.0
+        qn = (self.q_raw / self.q_raw.norm(dim=1, keepdim=True)).cpu()
+        gp = torch.Generator(device="cpu"); gp.manual_seed(2)
+        self.planted = torch.randperm(n_total, generator=gp)[: nq * 3].reshape(nq, 3)
+        near = qn[:, None, :] + torch.randn((nq, 3, 128), generator=gp) * 0.02
+        near = near / near.norm(dim=2, keepdim=True)
+        flat = self.planted.reshape(-1)
+        mine = (flat >= lo) & (flat < hi)
+        if mine.any():
+            self.db[(flat[mine] - lo).to(dev)] = near.reshape(-1, 128)[mine].to(dev)
+        self.q = torch.empty_like(self.q_raw)
+        self.ws = torch.empty_like(ops.TopKWorkspace(dev).get(self.n_local, nq, k))
+        self.ex = sharded.PackedExchange(nq, k, dev)     # this rank's results are written straight into its all-gather block
+
+    def step(self, events=None):
+        ops, ex = self.ops, self.ex
+        self.q.copy_(self.q_raw)                                            # the batch's raw embeddings (what the encoder hands over)
+        ops.l2_normalize_rows_(self.q, 1e-12)                               # F.normalize (dbsearch.py:303-304)
+        ops.ip_topk_prepare(self.db, self.q, self.k, self.ws)               # sample pass (lower bound per query)
+        if events is not None:
+            events[0].record()
+        ops.ip_topk_scan(self.db, self.q, self.k, self.ws)                  # dominant kernel: ONE scan launch
+        if events is not None:
+            events[1].record()
+        ops.ip_topk_finish(self.n_local, self.nq, self.k, self.ws, ex.out_s, ex.out_i, row_offset=self.lo)
+        if self.exchange:
+            ex.exchange()                                                   # ONE RCCL all-gather of 12*nq*k bytes per rank
+            return ex.merge()                                               # merge of the S blocks in place
+        return ex.out_s, ex.out_i
+
+    def fence(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def run(self, steps, warmup, prep_budget_s=0.3):
+        """-> (seconds for `steps` steps [max over ranks], mean scan-launch ms [max over ranks], last result)."""
+        torch = self.torch
+        self.step(); self.fence()
+        t = time.perf_counter(); self.step(); self.fence(); est = time.perf_counter() - t
+        for _ in range(min(40, int(prep_budget_s / max(est, 1e-4)))):       # untimed preparation, like the data generation:
+            self.step()                                                     # the GPU leaves its idle clocks within ~20 launches
+        for _ in range(warmup):
+            res = self.step()
+        self.fence()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        t0 = time.perf_counter()
+        for s in range(steps):
+            res = self.step(evs[s])
+        self.fence()
+        elapsed = time.perf_counter() - t0
+        scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        if self.world > 1:
+            t = torch.tensor([elapsed, scan_ms], dtype=torch.float64, device=self.db.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            elapsed, scan_ms = float(t[0]), float(t[1])
+        return elapsed, scan_ms, res
+
+    def check(self, res, sharded):
+        """Correctness of what was timed, after the timed region: recall@k against an exact brute force
+        (torch matmul + topk over every shard, merged over the ranks) -- for every query when the score
+        matrix is affordable, else for the first 64 -- and the planted neighbours."""
+        torch, k = self.torch, self.k
+        fs, fi = res
+        fi_c = fi.cpu()
+        planted = float(np.mean([len(set(self.planted[j].tolist()) & set(fi_c[j].tolist())) / 3.0 for j in range(self.nq)]))
+        nb = self.nq if self.n_local * self.nq <= (1 << 34) else min(self.nq, 64)
+        kk = min(k + 4, max(self.n_local, 1))
+        qn = self.q_raw[:nb] / self.q_raw[:nb].norm(dim=1, keepdim=True)
+        bs = bi = None
+        chunk = max(1, min(self.n_local, (1 << 31) // max(nb, 1)))
+        for r0 in range(0, self.n_local, chunk):
+            top = torch.topk(qn @ self.db[r0:r0 + chunk].T, min(kk, self.n_local - r0), dim=1)
+            idx = top.indices + (r0 + self.lo)
+            if bs is None:
+                bs, bi = top.values, idx
+            else:
+                cs, ci = torch.cat([bs, top.values], 1), torch.cat([bi, idx], 1)
+                keep = torch.topk(cs, min(kk, cs.shape[1]), dim=1)
+                bs, bi = keep.values, torch.gather(ci, 1, keep.indices)
+        if self.world > 1:
+            gs, gi = sharded.allgather_results(bs.contiguous(), bi.contiguous())
+            bs, bi = self.ops.topk_merge(gs, gi)
+        bs, bi, got = bs.cpu().numpy(), bi.cpu().numpy(), fi_c[:nb].numpy()
+        kth = bs[:, min(k, bs.shape[1]) - 1]
+        recall, identical = [], 0
+        for j in range(nb):
+            ok = set(bi[j][bs[j] >= kth[j] - 1e-6].tolist())               # rows tied with the k-th within 1e-6 are interchangeable
+            recall.append(len(ok & set(got[j].tolist())) / float(min(k, bs.shape[1])))
+            identical += int(np.array_equal(got[j], bi[j, :k]))
+        return {"recall_at_k": float(np.mean(recall)), "recall_queries_checked": nb,
+                "topk_identical_to_torch_bruteforce": "%d of %d queries" % (identical, nb), "planted_recall": planted}
+
+
+def hbm_regime(make, rows_list, log):
+    """nq = 1 / 8 / 32 (one query tile: the reference's own CLI usage, dbsearch.py:531-546) -- GB/s of the scan
+    launch and of the whole step against the 8 TB/s HBM peak."""
+    out = []
+    for rows in rows_list:
+        for nq in (1, 8, 32):
+            b = make(rows, nq)
+            steps = 40 if rows <= 4_000_000 else 6
+            elapsed, scan_ms, _ = b.run(steps, 3, prep_budget_s=0.05)
+            ms = elapsed / steps * 1e3
+            out.append({"rows": rows, "nq": nq, "k": b.k, "ms_per_step": ms, "scan_ms": scan_ms, "queries_per_s": nq / ms * 1e3,
+                        "scan_GBps": 512.0 * rows / scan_ms / 1e6, "scan_frac_of_hbm_peak": 512.0 * rows / (scan_ms * 1e-3) / HBM_PEAK,
+                        "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k)})
+            log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s), step %.3f ms" % (rows, nq, scan_ms, out[-1]["scan_frac_of_hbm_peak"] * 100, ms))
+            del b
+    return out
+
+
+def embed_bench(torch, ops, log):
+    """C3's embed half (1000 TED-length domains in ragged launches) and the C5 query."""
+    from merizo_search_amd.foldclass import synthetic as syn, weights as W
+    from merizo_search_amd.foldclass.chopping import domains_from_chopping
+    sd = W.synthetic_state_dict(0)
+    weights, pe = W.pack_state_dict(sd)
+    enc = ops.EgnnEncoder(weights, pe, "cuda:0")
+    lens = syn.ted_lengths(1000, seed=5)
+    coords = [syn.random_walk(int(n), seed=9000 + i) for i, n in enumerate(lens)]
+    flops = float(sum(2.0 * (263680.0 * n * n + 525312.0 * n) for n in lens.astype(np.float64)))    # SURVEY.md 8d (restructured minimum)
+
+    def timed(batch, reps):
+        enc.embed(batch); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); enc.embed(batch); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+        return float(np.median(ts))
+
+    t1000 = timed(coords, 3)
+    out = {"workload": "1000 synthetic domains, TED length distribution (sum N^2 = %.3g), 2-layer EGNN, ragged launches" % float((lens.astype(np.float64) ** 2).sum()),
+           "seconds": t1000, "embeds_per_s": 1000.0 / t1000, "algorithmic_tflops": flops / t1000 / 1e12,
+           "roofline": {"bound": "mfma", "achieved": flops / t1000 / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                        "frac": flops / t1000 / MFMA_F32_PEAK, "kernel": "ms_egnn_edge_kernel (+ proj / node / pool: whole encoder timed)",
+                        "algorithmic_flops": flops}}
+    pdb = os.path.join(REPO, "tests", "golden", "AF-Q96PD2-F1-model_v4_ca.pdb")
+    if os.path.exists(pdb):
+        doms = domains_from_chopping(pdb, "71-189,190-290,291-453", "A")
+        t3 = timed([d["coords"] for d in doms], 20)
+        out["c5_query"] = {"structure": "AF-Q96PD2 (775 residues), chopping 71-189,190-290,291-453", "domain_lengths": [len(d["seq"]) for d in doms],
+                           "embed_ms_three_domains": t3 * 1e3}
+        whole = np.concatenate([d["coords"] for d in domains_from_chopping(pdb, "1-775", "A")])
+        tw = timed([whole], 10)
+        fw = 2.0 * (263680.0 * len(whole) ** 2 + 525312.0 * len(whole))
+        out["c5_query"]["embed_ms_whole_chain_N%d" % len(whole)] = tw * 1e3
+        out["c5_query"]["whole_chain_frac_of_mfma_peak"] = fw / tw / MFMA_F32_PEAK
+    log("embed: %.1f ms per 1000 domains = %.0f embeds/s = %.1f%% of fp32 MFMA peak" % (t1000 * 1e3, out["embeds_per_s"], out["roofline"]["frac"] * 100))
+    return out, sd, coords
+
+
+def cpu_baseline(db, q_unit, k, n_total, sd, embed_coords):
+    """CPU legs on this host (baseline only).  `value`: the oracle's faiss-path port (oracle.c:orc_ip_topk, OpenMP +
+    AVX2 FMA, all cores) on the first rows of the same database and the same query batch, scaled linearly in rows.
+    `torch_cpu`: the reference's own torch op shapes (oracle/torch_baseline.py)."""
+    from oracle import oracle as orc
+    from oracle import torch_baseline as tb
+    cores = orc.num_threads()
+    qh = q_unit.cpu().numpy()
+    sample = min(db.shape[0], 50_000)
+    dbh = db[:sample].cpu().numpy()
+    t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
+    sample2 = int(min(db.shape[0], max(sample, sample * 5.0 / max(dt, 1e-3))))     # aim for ~5 s of wall time
+    if sample2 > sample:
+        dbh = db[:sample2].cpu().numpy()
+        t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
+        sample = sample2
+    model = ""
+    try:
+        model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+    except Exception:
+        pass
+    out = {"value": qh.shape[0] / (dt * n_total / sample), "unit": "queries/s", "cores": cores, "kind": "port",
+           "sample": "first %d of %d rows x all %d queries, %.2f s wall, scaled linearly in rows" % (sample, n_total, qh.shape[0], dt),
+           "host": {"nproc": os.cpu_count(), "cpu_model": model}}
+    rows_t = min(db.shape[0], 1_000_000)
+    torch_legs = tb.time_search_legs(db[:rows_t].cpu().numpy(), qh, k, n_total)
+    if sd is not None:
+        torch_legs["egnn_batch1_loop"] = tb.time_egnn_leg(sd, embed_coords[:200], budget_s=10.0)
+    out["torch_cpu"] = torch_legs
+    return out
 
 
 def main():
@@ -44,17 +272,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--rows", type=int, default=1_000_000, help="total database rows (sharded over the ranks)")
-    ap.add_argument("--nq", type=int, default=256)
+    ap.add_argument("--rows", type=int, default=None, help="TOTAL database rows, sharded over the ranks (default: 1M at N=1; 45,625,000 PER GPU at N>1)")
+    ap.add_argument("--nq", type=int, default=None, help="queries per step (default 256 at N=1, 4096 at N>1)")
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="after the timed region, also time the same steps with two batches in flight (reported as `pipelined`)")
+    ap.add_argument("--no-extras", action="store_true", help="skip hbm_regime / c4_shard / embed")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="query batches in flight: consecutive steps alternate over this many HIP streams, each with its own "
-                         "workspace (batch i+1's short kernels fill the tail of batch i's scan)")
     args = ap.parse_args()
 
     import torch
@@ -67,8 +291,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
     from merizo_search_amd import _lib, ops
-    from merizo_search_amd.foldclass import synthetic as syn
-    from merizo_search_amd.foldclass.sharded import PackedExchange, allgather_results, shard_bounds
+    from merizo_search_amd.foldclass import sharded, synthetic as syn
 
     _lib.require_gpu()                                   # fails loudly without the HIP library / a GPU
     # self-test hooks (one-GPU boxes): MS_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
@@ -84,173 +307,103 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    n_total, nq, k = args.rows, args.nq, args.k
-    lo, hi = shard_bounds(n_total, world, rank)
-    n_local = hi - lo
-
-    # ---- synthetic inputs, resident in HBM: unit rows ~ N(0,1)/|.|, seed 0;
-    # queries seed 1; 3 planted near-duplicates per query at known global rows.
-    db = syn.device_database(n_local, lo, seed=0, device=dev, normalize=True)
-    g = torch.Generator(device=dev); g.manual_seed(1)
-    q = torch.randn((nq, 128), generator=g, device=dev, dtype=torch.float32)
-    q = q / q.norm(dim=1, keepdim=True)
-    gp = torch.Generator(device="cpu"); gp.manual_seed(2)
-    planted_rows = torch.randperm(n_total, generator=gp)[: nq * 3].reshape(nq, 3)
-    noise = torch.randn((nq, 3, 128), generator=gp) * 0.02
-    planted = q.cpu()[:, None, :] + noise
-    planted = planted / planted.norm(dim=2, keepdim=True)
-    flat_rows = planted_rows.reshape(-1)
-    mine = (flat_rows >= lo) & (flat_rows < hi)
-    if mine.any():
-        db[(flat_rows[mine] - lo).to(dev)] = planted.reshape(-1, 128)[mine].to(dev)
-
-    n_pipes = max(1, args.streams)
-    pipes = []
-    for _ in range(n_pipes):
-        ex = PackedExchange(nq, k, dev)    # this rank's results are written straight into its all-gather block
-        pipes.append({"ws": torch.empty_like(ops.TopKWorkspace(dev).get(n_local, nq, k)), "ex": ex,
-                      "stream": torch.cuda.Stream(device=dev) if n_pipes > 1 else torch.cuda.current_stream(dev)})
-    shard_merge = ops.topk_merge
-    step_no = [0]
-
-    def step(events=None):
-        pipe = pipes[step_no[0] % n_pipes]
-        step_no[0] += 1
-        ws, ex = pipe["ws"], pipe["ex"]
-        with torch.cuda.stream(pipe["stream"]):
-            ops.ip_topk_prepare(db, q, k, ws)                               # queries + sample pass (lower bound)
-            if events is not None:
-                events[0].record()
-            ops.ip_topk_scan(db, q, k, ws)                                  # dominant kernel: ONE scan launch
-            if events is not None:
-                events[1].record()
-            ops.ip_topk_finish(n_local, nq, k, ws, ex.out_s, ex.out_i, row_offset=lo)
-            if world > 1 or args.exercise_exchange:
-                ex.exchange()                                               # ONE RCCL all-gather of 12*nq*k bytes per rank
-                return ex.merge()                                           # merge of the S blocks in place
-            return ex.out_s, ex.out_i
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(40):          # untimed preparation like the data generation above: the GPU leaves its idle clocks
-        step()                   # within the first ~20 launches, whatever --warmup is
-    for _ in range(args.warmup):
-        res = step()
-    fence()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for s in range(args.steps):
-        res = step(evs[s])
-    fence()
-    elapsed = time.perf_counter() - t0
-    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    if world > 1:
-        t = torch.tensor([elapsed, scan_ms], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, scan_ms = float(t[0]), float(t[1])
-
-    # ---- after the timed region (not part of `value`): the same steps with two batches in flight
-    pipelined = None
-    if world == 1 and n_pipes == 1 and args.pipelined:
-        extra = {"ws": torch.empty_like(pipes[0]["ws"]), "ex": PackedExchange(nq, k, dev), "stream": torch.cuda.Stream(device=dev)}
-        first = dict(pipes[0], stream=torch.cuda.Stream(device=dev))
-        saved, pipes[:] = list(pipes), [first, extra]
-        n_pipes = 2
-        psteps = max(20, min(args.steps, 100))
-        for _ in range(10):
-            step()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(psteps):
-            step()
-        fence()
-        dt = time.perf_counter() - t1
-        pipelined = {"batches_in_flight": 2, "steps": psteps, "value": nq * psteps / dt, "unit": "queries/s",
-                     "ms_per_step": dt / psteps * 1e3,
-                     "note": "same steps alternating over two HIP streams with their own workspaces, timed after the main region"}
-        pipes[:] = saved
-        n_pipes = 1
-
-    # ---- correctness of what was timed: planted rows recalled, exact top-k on a query sample
-    fs, fi = res
-    fi_c = fi.cpu()
-    recall = float(np.mean([len(set(planted_rows[j].tolist()) & set(fi_c[j].tolist())) / 3.0 for j in range(nq)]))
-    sample = min(nq, 8)
-    ref = (q[:sample] @ db.T).topk(min(k, n_local), dim=1)
+    k = args.k
+    weak = world > 1 and args.rows is None
     if world == 1:
-        exact = bool(torch.equal(ref.indices + lo, fi[:sample]))
+        n_total, nq = args.rows or 1_000_000, args.nq or 256
     else:
-        gs, gi = allgather_results(ref.values.contiguous(), (ref.indices + lo).contiguous())
-        ms_, mi_ = shard_merge(gs, gi)
-        exact = bool(torch.equal(mi_, fi[:sample]))
+        rows_per_gpu = int(os.environ.get("MS_BENCH_ROWS_PER_GPU", C4_ROWS_PER_GPU))
+        n_total, nq = args.rows or rows_per_gpu * world, args.nq or C4_NQ
+    lo, hi = sharded.shard_bounds(n_total, world, rank)
+    log = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
+
+    bench = SearchBench(torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=args.exercise_exchange)
+    steps = args.steps
+    elapsed, scan_ms, res = bench.run(steps, args.warmup)
+    checks = bench.check(res, sharded)
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = nq * args.steps / elapsed
-        scan_rows = n_local                                                     # the timed launch scans every row of the shard
-        flops = 2.0 * 128 * nq * scan_rows
-        bytes_ = 512.0 * scan_rows
-        t_scan = scan_ms * 1e-3
-        mfma_frac = flops / t_scan / MFMA_F32_PEAK
-        hbm_frac = bytes_ / t_scan / HBM_PEAK
-        if nq >= 39:      # fp32-MFMA-bound above ~39 queries per pass
-            roof = {"bound": "mfma", "achieved": flops / t_scan / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
-                    "frac": mfma_frac, "traffic": None}
-        else:
-            roof = {"bound": "hbm", "achieved": bytes_ / t_scan / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                    "frac": hbm_frac, "traffic": None}
-        roof.update({"kernel": "ms_scan_loader_kernel" if (nq > 64 and k <= 20) else "ms_scan_kernel", "kernel_ms": scan_ms,
-                     "mfma_frac": mfma_frac, "hbm_frac": hbm_frac, "rows_per_launch": scan_rows,
-                     "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
-        # HBM traffic of one launch of that kernel from the committed PMC passes of this same command
-        # (profiles/: separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction applied)
-        pmc = os.path.join(REPO, "profiles", "r01_c2_pmc_v9.json")
+        ms_per_step = elapsed / steps * 1e3
+        roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
+        # HBM traffic of one launch of that kernel: PMC passes of this same command committed under profiles/
+        # (separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction); not measured live
+        pmc = os.path.join(REPO, "profiles", "r02_c2_pmc.json")
         if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10) and os.path.exists(pmc):
             with open(pmc) as fh:
                 roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r01_c2_pmc_v9.json"
+            roof["traffic_source"] = "profiles/r02_c2_pmc.json (committed rocprofv3 --pmc passes of this command, not measured in this run)"
+        if (n_total, nq, world) == (1_000_000, 256, 1):
+            workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
+        elif weak:
+            workload = "C4 shape: TED-scale %d x 128 fp32 synthetic DB row-sharded over %d GPUs (%d rows each), batch=%d queries, top-%d, RCCL all-gather of per-shard top-k" % (
+                n_total, world, bench.n_local, nq, k)
+        else:
+            workload = "cosine top-%d, %d x 128 fp32 synthetic DB, batch=%d queries, %d GPU(s)" % (k, n_total, nq, world)
         line = {
-            "metric": "queries/sec (exact 128-d cosine top-k, recall@k vs brute force = %.3f)" % recall,
-            "value": value, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("C2: brute-force cosine top-%d, %d x 128 fp32 synthetic DB, batch=%d queries" % (k, n_total, nq))
-                       if (n_total, nq) == (1_000_000, 256) else ("cosine top-%d, %d x 128 fp32 synthetic DB, batch=%d queries" % (k, n_total, nq)),
-                       "db_rows": n_total, "dim": 128, "queries_per_step": nq, "k": k, "score": "inner product of unit rows",
-                       "sharding": "contiguous row shards, %d rows/GPU, RCCL all-gather of per-shard top-k" % n_local if world > 1 else "single shard"},
-            "recall_at_k": recall, "topk_exact_on_sample": exact, "batches_in_flight": n_pipes, "pipelined": pipelined,
+            "metric": "queries/sec, exact 128-d cosine top-%d (recall@%d vs brute force = %.4f)" % (k, k, checks["recall_at_k"]),
+            "value": nq * steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": workload, "db_rows": n_total, "rows_per_gpu": bench.n_local, "dim": 128, "queries_per_step": nq, "k": k,
+                       "score": "inner product of L2-normalised rows (normalisation of the query batch inside the step)",
+                       "sharding": "contiguous row shards, one RCCL all-gather of per-shard top-k + merge per step" if world > 1 else "single shard",
+                       "scaling_note": "weak: rows per GPU fixed, the database grows with N, so ideal queries/s is CONSTANT in N (row x query "
+                                       "rate grows N-fold); compare with c4_shard of the N=1 run" if weak else None},
+            "row_queries_per_s": float(n_total) * nq * steps / elapsed,
             "roofline": roof,
         }
+        line.update(checks)
+    else:
+        line = None
+
+    extras_sd, extras_coords = None, None
+    if world == 1 and not args.no_extras:
+        db_keep, q_keep = bench.db, bench.q_raw
+        del bench.ws
+        mk = lambda rows, nq_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k)
+        line["hbm_regime"] = hbm_regime(mk, (1_000_000,), log)
+        free, _tot = torch.cuda.mem_get_info(dev)
+        if free > 40 << 30:
+            big = mk(C4_ROWS_PER_GPU, C4_NQ)
+            el, sc, r4 = big.run(2, 1, prep_budget_s=0.0)
+            ms4 = el / 2 * 1e3
+            fi4 = r4[1].cpu()
+            planted4 = float(np.mean([len(set(big.planted[j].tolist()) & set(fi4[j].tolist())) / 3.0 for j in range(C4_NQ)]))
+            line["c4_shard"] = {"workload": "one rank's share of C4: %d x 128 rows x %d queries, top-%d" % (C4_ROWS_PER_GPU, C4_NQ, k),
+                                "ms_per_step": ms4, "queries_per_s": C4_NQ / ms4 * 1e3, "planted_recall": planted4,
+                                "note": "queries_per_s here = the N-GPU rate on an N x 45.6M-row database, minus the all-gather + merge of 480 KB per rank",
+                                "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
+            log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s, scan %.1f%% of fp32 MFMA peak" % (ms4, C4_NQ / ms4 * 1e3, line["c4_shard"]["roofline"]["frac"] * 100))
+            # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
+            small = []
+            for nq_ in (1, 8, 32):
+                b = SearchBench.__new__(SearchBench)
+                b.__dict__.update(big.__dict__)
+                b.nq, b.q_raw = nq_, big.q_raw[:nq_].contiguous()
+                b.q = torch.empty_like(b.q_raw)
+                b.ws = torch.empty_like(ops.TopKWorkspace(dev).get(b.n_local, nq_, k))
+                b.ex = sharded.PackedExchange(nq_, k, dev)
+                el, sc, _ = b.run(6, 2, prep_budget_s=0.0)
+                ms = el / 6 * 1e3
+                small.append({"rows": C4_ROWS_PER_GPU, "nq": nq_, "k": k, "ms_per_step": ms, "scan_ms": sc, "queries_per_s": nq_ / ms * 1e3,
+                              "scan_GBps": 512.0 * C4_ROWS_PER_GPU / sc / 1e6, "scan_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (sc * 1e-3) / HBM_PEAK,
+                              "step_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq_, k)})
+                log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s)" % (C4_ROWS_PER_GPU, nq_, sc, small[-1]["scan_frac_of_hbm_peak"] * 100))
+                del b
+            line["hbm_regime"] += small
+            del big, r4
+            torch.cuda.empty_cache()
+        line["embed"], extras_sd, extras_coords = embed_bench(torch, ops, log)
+        bench.db, bench.q_raw = db_keep, q_keep
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(db, q, k, n_total)
+            q_unit = bench.q_raw / bench.q_raw.norm(dim=1, keepdim=True)
+            line["cpu_baseline"] = cpu_baseline(bench.db, q_unit, k, n_total, extras_sd, extras_coords)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def cpu_baseline(db, q, k, n_total):
-    """The CPU oracle's faiss-path restatement (oracle.c:orc_ip_topk, OpenMP + AVX2 FMA) on the
-    host cores, on the first `sample` rows of the same database and the same query batch."""
-    from oracle import oracle as orc
-    cores = orc.num_threads()
-    qh = q.cpu().numpy()
-    sample = min(db.shape[0], 50_000)
-    dbh = db[:sample].cpu().numpy()
-    t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
-    # aim for ~5 s of wall time on the final sample
-    sample2 = int(min(db.shape[0], max(sample, sample * 5.0 / max(dt, 1e-3))))
-    if sample2 > sample:
-        dbh = db[:sample2].cpu().numpy()
-        t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
-        sample = sample2
-    value = qh.shape[0] / (dt * n_total / sample)
-    return {"value": value, "unit": "queries/s", "cores": cores, "kind": "port",
-            "sample": "first %d of %d rows x all %d queries, %.2f s wall, scaled linearly in rows" % (sample, n_total, qh.shape[0], dt)}
 
 
 if __name__ == "__main__":

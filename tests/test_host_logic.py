@@ -282,3 +282,54 @@ def test_device_cpu_is_refused():
     assert resolve_device("cuda") == "cuda:0" and resolve_device("cuda:3") == "cuda:3"
     with pytest.raises(SystemExit):
         resolve_device("cpu")
+
+
+def test_c1_real_size_search_through_the_cli_on_the_oracle_engine(tmp_path, monkeypatch, golden_dir):
+    """BASELINE config C1 at its real size: `search examples/M0.pdb` against the shipped TED example
+    database layout (66,943 entries; name / offset files byte-identical to the shipped ones, payloads
+    synthesised to the shipped byte counts), CPU plumbing run with the oracle engine."""
+    import c1_case
+    from oracle_engine import oracle_network
+    from merizo_search_amd import cli
+    from merizo_search_amd.foldclass import dbsearch as ds
+    net = oracle_network()
+    m0 = os.path.join(golden_dir, "M0_ca.pdb")
+    p = np.load(os.path.join(golden_dir, "pdb_M0.npz"))
+    e = net.embed_many([p["coords"]]).numpy()[0]
+    e = (e / np.linalg.norm(e)).astype(np.float32)
+    rng = np.random.default_rng(1)
+    planted = {}
+    for j, row in enumerate((66942, 0, 31337)):                # best, second, third: first / last rows included
+        v = e + 0.02 * (j + 1) * rng.standard_normal(128).astype(np.float32) / np.sqrt(128)
+        planted[row] = (v / np.linalg.norm(v)).astype(np.float32)
+    prefix = c1_case.build(str(tmp_path / "db"), plant=planted)
+    monkeypatch.setattr(ds, "network_setup", lambda **kw: (net, "cpu"))
+    cli.main(["search", m0, prefix, str(tmp_path / "out"), str(tmp_path / "tmp"), "-k", "5", "-s", "-1", "--output_headers",
+              "--format", "query,emb_rank,target,emb_score,q_len,t_len,metadata"])
+    c1_case.check_search(str(tmp_path / "out"), [66942, 0, 31337], 5)
+
+
+def test_checkpoint_round_trip_through_network_setup(tmp_path):
+    """The real-checkpoint branch (reference dbsearch.py:43: torch.load of a state_dict, strict=False):
+    torch.save -> find_checkpoint -> load_checkpoint -> pack_state_dict reproduces the weights, ignores
+    extra keys, and network_setup embeds with them."""
+    import torch
+    from oracle_engine import OracleEngine
+    from merizo_search_amd.foldclass import network as nw, weights as W, synthetic as syn
+    sd = W.synthetic_state_dict(3)
+    ckpt = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    ckpt["not_a_model_key"] = torch.zeros(3)                            # strict=False: ignored
+    path = str(tmp_path / nw.WEIGHTS_NAME)
+    torch.save(ckpt, path)
+    w0, pe0 = W.pack_state_dict(sd)
+    w1, pe1 = W.pack_state_dict(W.load_checkpoint(path))
+    assert np.array_equal(w0, w1) and np.array_equal(pe0, pe1)
+    assert nw.find_checkpoint(path) == path
+    net, _dev = nw.network_setup(device="cuda", weights_path=path, engine=OracleEngine())
+    coords = syn.random_walk(40, seed=4)
+    want = nw.FoldClassEncoder(OracleEngine(sd)).embed_many([coords]).numpy()
+    assert np.array_equal(net(coords[None]).numpy(), want)
+    del ckpt["encode_ca_egnn.0.edge_mlp.0.weight"]
+    torch.save(ckpt, path)
+    with pytest.raises(KeyError):
+        W.pack_state_dict(W.load_checkpoint(path))

@@ -135,3 +135,25 @@ def test_topk_merge_and_padding():
     s, i = orc.topk_merge(np.stack(parts_s), np.stack(parts_i))
     s_full, i_full = orc.ip_topk(db, q, 10)
     assert np.array_equal(s, s_full) and np.array_equal(i, i_full)
+
+
+def test_torch_cpu_baseline_legs_are_the_reference_arithmetic(golden_dir):
+    """oracle/torch_baseline.py (the torch-CPU legs bench.py times next to the GPU) against the
+    reference-derived goldens: EGNN embedding of M0 (G1), cosine+mask top-k (G2), blockwise IP top-k."""
+    import torch
+    from oracle import torch_baseline as tb
+    from merizo_search_amd.foldclass import weights as W
+    g = np.load(os.path.join(golden_dir, "egnn.npz"))
+    sd = tb.state_dict_tensors(W.synthetic_state_dict(0))
+    p = np.load(os.path.join(golden_dir, "pdb_M0.npz"))
+    e = tb.egnn_forward(sd, torch.from_numpy(p["coords"])[None]).numpy()[0]
+    ref = g["emb_M0"]
+    assert np.abs(e - ref).max() <= 1e-6 * np.abs(ref).max()
+    s = np.load(os.path.join(golden_dir, "search.npz"))
+    db, lengths = syn.raw_database(5000, seed=11)
+    q, qlen = syn.raw_queries(8, seed=12)
+    ts, ti = tb.pt_path_search(torch.from_numpy(db), torch.from_numpy(lengths), torch.from_numpy(q), qlen, 0.7, 10)
+    assert_topk_equivalent(ts.numpy(), ti.numpy(), s["s_cov0.7_k10"], s["i_cov0.7_k10"], tol=3e-7)
+    dbn = orc.l2_normalize_rows(db, 1e-12)
+    fs, fi = tb.faiss_path_search(torch.from_numpy(dbn), torch.from_numpy(q), 10, block=777)
+    assert_topk_equivalent(fs.numpy(), fi.numpy(), s["s_prenorm_k10"], s["i_prenorm_k10"], tol=3e-7)

@@ -28,7 +28,7 @@ One JSON line is printed by rank 0 (contract in the task statement), with
                 cores, and under `torch_cpu` the reference's own torch op shapes (oracle/torch_baseline.py)
                 -- per-query cosine_similarity*mask->topk, blockwise-262,144 normalize->Q@D^T->topk->merge,
                 batch=1 EGNN loop; all on bounded samples;
-  hbm_regime    (N = 1) nq = 1 / 8 / 32 over 1M and 45.6M rows: GB/s against the HBM peak;
+  hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M and 45.6M rows: GB/s against the HBM peak;
   c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
                 peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
@@ -179,11 +179,11 @@ class SearchBench:
 
 
 def hbm_regime(make, rows_list, log):
-    """nq = 1 / 8 / 32 (one query tile: the reference's own CLI usage, dbsearch.py:531-546) -- GB/s of the scan
+    """nq = 1 / 4 / 8 / 32 (few queries / one query tile: the reference's own CLI usage, dbsearch.py:531-546) -- GB/s of the scan
     launch and of the whole step against the 8 TB/s HBM peak."""
     out = []
     for rows in rows_list:
-        for nq in (1, 8, 32):
+        for nq in (1, 4, 8, 32):
             b = make(rows, nq)
             steps = 40 if rows <= 4_000_000 else 6
             elapsed, scan_ms, _ = b.run(steps, 3, prep_budget_s=0.05)
@@ -376,7 +376,7 @@ def main():
             log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s, scan %.1f%% of fp32 MFMA peak" % (ms4, C4_NQ / ms4 * 1e3, line["c4_shard"]["roofline"]["frac"] * 100))
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
             small = []
-            for nq_ in (1, 8, 32):
+            for nq_ in (1, 4, 8, 32):
                 b = SearchBench.__new__(SearchBench)
                 b.__dict__.update(big.__dict__)
                 b.nq, b.q_raw = nq_, big.q_raw[:nq_].contiguous()

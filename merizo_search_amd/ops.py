@@ -87,8 +87,10 @@ class TopKWorkspace:
 
 
 def ip_topk(db, q, k: int, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=None, qlen=None,
-            mincov: float = 0.0, row_offset: int = 0, workspace: Optional[TopKWorkspace] = None):
-    """Exact top-k of q [nq,128] against db [n,128] -> (scores f32 [nq,k], idx i64 [nq,k])."""
+            mincov: float = 0.0, row_offset: int = 0, workspace=None, out=None):
+    """Exact top-k of q [nq,128] against db [n,128] -> (scores f32 [nq,k], idx i64 [nq,k]).
+    workspace: a TopKWorkspace (grown on demand) or a uint8 tensor of ms_ip_topk_workspace_bytes;
+    out: optional preallocated (scores, idx) tensors."""
     torch = _lib.require_gpu()
     _f32_cuda(db, "db", DIM)
     _f32_cuda(q, "q", DIM)
@@ -98,10 +100,16 @@ def ip_topk(db, q, k: int, mode: int = MODE_IP_PRENORM, inv_norm=None, lengths=N
             _f32_cuda(t, name)
             if t.numel() != size:
                 raise MerizoHipError(f"{name}: expected {size} elements, got {t.numel()}")
-    ws = (workspace or TopKWorkspace(db.device)).get(n, nq, k)
-    out_s = torch.empty((nq, k), dtype=torch.float32, device=db.device)
-    out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
-    with _on(db, q, inv_norm, lengths, qlen, ws) as dev:
+    ws = workspace if isinstance(workspace, torch.Tensor) else (workspace or TopKWorkspace(db.device)).get(n, nq, k)
+    if out is None:
+        out_s = torch.empty((nq, k), dtype=torch.float32, device=db.device)
+        out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
+    else:
+        out_s, out_i = out
+        if (tuple(out_s.shape) != (nq, k) or tuple(out_i.shape) != (nq, k) or out_s.dtype != torch.float32
+                or out_i.dtype != torch.int64 or not out_s.is_contiguous() or not out_i.is_contiguous()):
+            raise MerizoHipError("ip_topk: out must be contiguous (float32 [nq,k], int64 [nq,k]) tensors")
+    with _on(db, q, inv_norm, lengths, qlen, ws, out_s, out_i) as dev:
         check(_lib.load().ms_ip_topk(ptr(db), n, row_offset, ptr(q), nq, k, mode, ptr(inv_norm), ptr(lengths), ptr(qlen),
                                      mincov, ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk")
     return out_s, out_i

@@ -134,7 +134,6 @@ def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
     s32, i32 = ops.ip_topk(db, q[:32], k, row_offset=lo)
     assert torch.equal(i1, i[:1]) and torch.equal(s1, s[:1]) and torch.equal(i32, i[:32]) and torch.equal(s32, s[:32])
 
-
 def test_c1_real_size_cli_search_on_gpu(tmp_path, golden_dir):
     """C1 at its real size through the CLI on the HIP engine: M0 against the shipped TED example layout
     (66,943 entries), three neighbours planted at the first / last / a middle row."""
@@ -198,7 +197,7 @@ import numpy as np, torch
 from merizo_search_amd import ops
 from merizo_search_amd.foldclass import synthetic as syn
 from oracle import oracle as orc
-for n, nq, k in ((300_000, 100, 10), (300_000, 4, 10), (40_000, 256, 33)):
+for n, nq, k in ((300_000, 100, 10), (300_000, 4, 10), (300_000, 20, 10), (40_000, 256, 33), (1_200_000, 130, 10)):
     db = syn.normalized_database(n, seed=5); q = syn.normalized_database(nq, seed=6)
     db[n - 1] = db[3]
     s, i = ops.ip_topk(torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda(), k)

@@ -28,7 +28,7 @@ One JSON line is printed by rank 0 (contract in the task statement), with
                 cores, and under `torch_cpu` the reference's own torch op shapes (oracle/torch_baseline.py)
                 -- per-query cosine_similarity*mask->topk, blockwise-262,144 normalize->Q@D^T->topk->merge,
                 batch=1 EGNN loop; all on bounded samples;
-  hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M and 45.6M rows: GB/s against the HBM peak;
+  hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M, 4M and 45.6M rows: GB/s against the HBM peak;
   c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
                 peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
@@ -247,17 +247,24 @@ def cpu_baseline(db, q_unit, k, n_total, sd, embed_coords):
     dbh = db[:sample].cpu().numpy()
     t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
     sample2 = int(min(db.shape[0], max(sample, sample * 5.0 / max(dt, 1e-3))))     # aim for ~5 s of wall time
+    reps = 1
     if sample2 > sample:
         dbh = db[:sample2].cpu().numpy()
         t = time.perf_counter(); orc.ip_topk(dbh, qh, k); dt = time.perf_counter() - t
         sample = sample2
+        reps = int(min(20, max(1, 2.0 / max(dt, 1e-3))))                           # whole database in well under a second: repeat
+        if reps > 1:
+            t = time.perf_counter()
+            for _ in range(reps):
+                orc.ip_topk(dbh, qh, k)
+            dt = (time.perf_counter() - t) / reps
     model = ""
     try:
         model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
     except Exception:
         pass
     out = {"value": qh.shape[0] / (dt * n_total / sample), "unit": "queries/s", "cores": cores, "kind": "port",
-           "sample": "first %d of %d rows x all %d queries, %.2f s wall, scaled linearly in rows" % (sample, n_total, qh.shape[0], dt),
+           "sample": "first %d of %d rows x all %d queries, %.2f s wall per pass (%d passes), scaled linearly in rows" % (sample, n_total, qh.shape[0], dt, reps),
            "host": {"nproc": os.cpu_count(), "cpu_model": model}}
     rows_t = min(db.shape[0], 1_000_000)
     torch_legs = tb.time_search_legs(db[:rows_t].cpu().numpy(), qh, k, n_total)
@@ -361,7 +368,7 @@ def main():
         db_keep, q_keep = bench.db, bench.q_raw
         del bench.ws
         mk = lambda rows, nq_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k)
-        line["hbm_regime"] = hbm_regime(mk, (1_000_000,), log)
+        line["hbm_regime"] = hbm_regime(mk, (1_000_000, 4_000_000), log)
         free, _tot = torch.cuda.mem_get_info(dev)
         if free > 40 << 30:
             big = mk(C4_ROWS_PER_GPU, C4_NQ)

@@ -5,26 +5,27 @@
 //   :213-248 knn_exact_faiss           IndexFlat(IP).search per block + ResultHeap merge
 //   :303-304 F.normalize(query_embeddings)
 //
-// Kernels
-//   ms_normalize_rows_kernel / ms_row_inv_norms_kernel   one wave per 512-byte row
-//   ms_scan_kernel<QW>   fused  S = D . Q^T  (fp32 MFMA 32x32x2)  +  per-query running top-k
-//   ms_partial_merge_kernel   per query: merge the per-chunk lists, emit float32/int64 results
-//   ms_kway_merge_kernel      public merge of S sorted lists (shards / blocks)
+// This file: normalisation kernels, the launch plan (row streams x query tiles, workspace carve), the two merges of
+// per-stream lists and the C entry points.  The scan kernels themselves live in ms_scan.h (instantiated per list
+// length in ms_scan_kl*.hip):
+//   ms_scan_loader_kernel<KL,AUX>    >= 3 query tiles (MFMA-bound): 4 compute waves share the rows a fifth wave streams
+//                                    into an LDS ring by LDS-DMA
+//   ms_scan_kernel<KL,AUX,UB>        1-2 query tiles (HBM-bound), k > 20, and passes with an upper bound (k > 64)
+//   ms_scan_sample_kernel<KL,AUX>    sample pass: best rows of the first tiles of every stream -> lower bound per query
+// Common to all of them: one wave = one (32-query tile, row stream) pair; the query tile is the MFMA B
+// operand in 64 VGPRs for the whole kernel; 32-row tiles arrive by LDS-DMA with an XOR-swizzled source so that the
+// lane = row ds_read_b128 A-fragment reads are conflict free; k-step s of the v_mfma_f32_32x32x2_f32 chain multiplies
+// elements k = s (lanes 0-31) and k = 64 + s (lanes 32-63), i.e. the accumulation order is s = 0..63: (k = s, k = 64 + s)
+// -- restated by oracle/oracle.c:dot_ordered(order = 1), which reproduces the scores bit for bit; the running top-k of a
+// query lives in the registers of its two lanes; rows are visited in ascending order, so "strictly greater than the k-th
+// best" is the exact (score desc, row asc) order.
 //
-// Scan kernel layout (see DESIGN.md "scan kernel"):
-//   * one workgroup = 4 waves; wave (qw, rw) owns query tile qw (32 queries, held for the
-//     whole kernel as the MFMA B operand in 64 VGPRs) and row sub-tile rw of the staged tile;
-//   * database rows stream HBM -> registers (16 B/lane, fully coalesced) -> LDS, XOR-swizzled
-//     so that the ds_read_b128 A-operand reads (lane = row) are bank-conflict free;
-//   * k-step s of the MFMA chain multiplies elements k = s (lanes 0-31) and k = 64 + s (lanes
-//     32-63): every lane then reads 4 consecutive floats of its row per ds_read_b128.  The
-//     accumulation order is therefore  s = 0..63: (k = s, k = 64 + s)  -- restated by
-//     oracle/oracle.c:dot_ordered(order = 1), which reproduces these scores bit for bit;
-//   * the 32x32 accumulator has the query on the lane (col = lane & 31) and 16 rows in
-//     registers, so the top-k filter is a per-lane compare against that query's current
-//     k-th best score; the rare survivors are inserted wave-cooperatively into a sorted
-//     list in LDS (ms_wave_insert).  Rows are visited in ascending order, so "strictly
-//     greater than the k-th best" is the exact (score desc, row asc) order.
+// Kernels here
+//   ms_normalize_rows_kernel / ms_row_inv_norms_kernel / ms_prepare_queries_kernel   one wave per 512-byte row
+//   ms_head_merge_kernel      per query: k rounds of "best list head wins" over the per-stream lists staged in LDS
+//   ms_partial_merge_kernel   the same merge for large k * P (does not fit LDS): threshold from the list heads + pool
+//   ms_kway_merge_kernel      public merge of S sorted lists (shards after the all-gather, blocks when streaming);
+//                             ms_kway_merge_any_kernel beyond 64 lists
 #include "ms_common.h"
 
 #include <math.h>
@@ -293,6 +294,40 @@ __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores0,
         const size_t oo = (size_t)q * k + j;
         if (best < 0) { out_s[oo] = -INFINITY; out_i[oo] = -1; }
         else { out_s[oo] = bs; out_i[oo] = bi; ++head[best]; }
+    }
+}
+
+// The same merge for any number of lists (S > 64: no per-thread head array): output j is the best entry that comes
+// strictly after output j-1 in the total order (score desc, index asc; indices are unique across the lists), found
+// by a linear walk of every sorted list.  O(k * S * k) per query: only used beyond 64 lists.
+__global__ __launch_bounds__(64) void ms_kway_merge_any_kernel(const float *scores0, const int64_t *idx0, int64_t score_stride,
+                                                               int64_t idx_stride, int S, int nq, int k, float *out_s,
+                                                               int64_t *out_i) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    bool have_prev = false;
+    float ps = 0.0f;
+    int64_t pi = 0;
+    for (int j = 0; j < k; ++j) {
+        bool found = false;
+        float bs = 0.0f;
+        int64_t bi = 0;
+        for (int s = 0; s < S; ++s) {
+            const float *ls = reinterpret_cast<const float *>(reinterpret_cast<const char *>(scores0) + (size_t)s * score_stride) + (size_t)q * k;
+            const int64_t *li = reinterpret_cast<const int64_t *>(reinterpret_cast<const char *>(idx0) + (size_t)s * idx_stride) + (size_t)q * k;
+            for (int e = 0; e < k; ++e) {
+                const int64_t ci = li[e];
+                if (ci < 0) break;                                   // padding: list exhausted
+                const float cs = ls[e];
+                if (have_prev && !(cs < ps || (cs == ps && ci > pi))) continue;   // not after the previous output
+                if (!found || cs > bs || (cs == bs && ci < bi)) { found = true; bs = cs; bi = ci; }
+                break;                                               // sorted list: its first entry after prev is its best one
+            }
+        }
+        const size_t oo = (size_t)q * k + j;
+        if (!found) { for (int r = j; r < k; ++r) { out_s[(size_t)q * k + r] = -INFINITY; out_i[(size_t)q * k + r] = -1; } return; }
+        out_s[oo] = bs; out_i[oo] = bi;
+        have_prev = true; ps = bs; pi = bi;
     }
 }
 
@@ -654,22 +689,30 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
 
 int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k, float *out_scores,
                   int64_t *out_idx, ms_stream_t stream) {
-    if (S < 1 || S > 64 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
-        MS_FAIL(MS_ERR_ARG, "ms_topk_merge: need 1 <= S <= 64, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
-    hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
-                       (int64_t)nq * k * 4, (int64_t)nq * k * 8, S, nq, k, out_scores, out_idx);
+    if (S < 1 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
+        MS_FAIL(MS_ERR_ARG, "ms_topk_merge: need S >= 1, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
+    if (S <= 64)
+        hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                           (int64_t)nq * k * 4, (int64_t)nq * k * 8, S, nq, k, out_scores, out_idx);
+    else
+        hipLaunchKernelGGL(ms_kway_merge_any_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                           (int64_t)nq * k * 4, (int64_t)nq * k * 8, S, nq, k, out_scores, out_idx);
     MS_LAUNCH_CHECK("ms_kway_merge_kernel");
     return MS_OK;
 }
 
 int ms_topk_merge_strided(const float *scores, const int64_t *idx, int64_t score_stride_bytes, int64_t idx_stride_bytes,
                           int S, int nq, int k, float *out_scores, int64_t *out_idx, ms_stream_t stream) {
-    if (S < 1 || S > 64 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
-        MS_FAIL(MS_ERR_ARG, "ms_topk_merge_strided: need 1 <= S <= 64, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
+    if (S < 1 || nq < 1 || k < 1 || !scores || !idx || !out_scores || !out_idx)
+        MS_FAIL(MS_ERR_ARG, "ms_topk_merge_strided: need S >= 1, nq >= 1, k >= 1 and non-NULL buffers (S=%d)", S);
     if (score_stride_bytes % 4 != 0 || idx_stride_bytes % 8 != 0 || ((uintptr_t)idx & 7) != 0)
         MS_FAIL(MS_ERR_ARG, "ms_topk_merge_strided: strides / index pointer must keep float32 and int64 alignment");
-    hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
-                       score_stride_bytes, idx_stride_bytes, S, nq, k, out_scores, out_idx);
+    if (S <= 64)
+        hipLaunchKernelGGL(ms_kway_merge_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                           score_stride_bytes, idx_stride_bytes, S, nq, k, out_scores, out_idx);
+    else
+        hipLaunchKernelGGL(ms_kway_merge_any_kernel, dim3((nq + 63) / 64), dim3(64), 0, (hipStream_t)stream, scores, idx,
+                           score_stride_bytes, idx_stride_bytes, S, nq, k, out_scores, out_idx);
     MS_LAUNCH_CHECK("ms_kway_merge_kernel");
     return MS_OK;
 }

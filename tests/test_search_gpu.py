@@ -324,3 +324,42 @@ def test_cosine_tiny_databases_partial_tiles(n, torch_gpu):
                            lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
         s_ref, i_ref = orc.cosine_topk(db, q, min(5, n), lengths, qlen, 0.7)
         assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+
+
+@pytest.mark.parametrize("S,nq,k", [(65, 9, 10), (200, 3, 1), (130, 40, 7)])
+def test_topk_merge_beyond_64_lists(S, nq, k, torch_gpu):
+    """ms_topk_merge with more than 64 lists (no per-thread head array) == the 64-list kernel applied in two levels
+    == the oracle's merge; padding entries and cross-list score ties included."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    rng = np.random.default_rng(S)
+    scores = np.sort(rng.standard_normal((S, nq, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    scores[3] = scores[70 % S]                                   # equal scores in two lists: the lower index wins
+    idx = rng.permutation(S * nq * k).astype(np.int64).reshape(S, nq, k)
+    idx.sort(axis=2)                                             # (ties inside a list stay in index order)
+    scores[5, :, k // 2:] = -np.inf; idx[5, :, k // 2:] = -1     # a short list
+    s, i = ops.topk_merge(_dev(torch, scores), _dev(torch, idx))
+    s_ref, i_ref = orc.topk_merge(scores, idx)
+    assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy(), s_ref)
+
+
+def test_nan_and_inf_rows_are_never_returned(torch_gpu):
+    """NaN policy (DESIGN.md 4): a database row whose score is NaN or -inf is never returned, whatever the kernel form;
+    +inf scores sort first.  (torch.topk would rank NaN first; the reference never produces one from finite embeddings.)"""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    for n, nq in ((5000, 3), (200_000, 100)):
+        db = _norm_db(n, seed=31)
+        q = _norm_db(nq, seed=32)
+        bad = np.array([0, 17, 33, n // 2, n - 1])
+        db[bad[:3], 5] = np.nan
+        db[bad[3]] = -np.inf                                     # -inf * (mixed signs) = NaN / -inf
+        db[bad[4], :] = np.nan
+        s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), 10)
+        s, i = s.cpu().numpy(), i.cpu().numpy()
+        assert np.isfinite(s).all() and not np.isin(i, bad).any()
+        keep = np.setdiff1d(np.arange(n), bad)
+        s_ref, i_ref = orc.ip_topk(db[keep], q, 10, order=1)
+        assert np.array_equal(i, keep[i_ref]) and np.array_equal(s.view(np.uint32), s_ref.view(np.uint32))

@@ -86,7 +86,9 @@ class SearchBench:
         self.q_raw = torch.randn((nq, 128), generator=g, device=dev, dtype=torch.float32) * 3.0
         qn = (self.q_raw / self.q_raw.norm(dim=1, keepdim=True)).cpu()
         gp = torch.Generator(device="cpu"); gp.manual_seed(2)
-        self.planted = torch.randperm(n_total, generator=gp)[: nq * 3].reshape(nq, 3)
+        # nq * 3 distinct pseudo-random global rows without materialising a permutation of n_total (365M at C4)
+        step_ = 2_147_483_629 if n_total % 2_147_483_629 else 2_147_483_587                    # primes: a bijection modulo n_total
+        self.planted = ((torch.arange(nq * 3, dtype=torch.int64) * step_ + 12_345) % n_total).reshape(nq, 3)
         near = qn[:, None, :] + torch.randn((nq, 3, 128), generator=gp) * 0.02
         near = near / near.norm(dim=2, keepdim=True)
         flat = self.planted.reshape(-1)

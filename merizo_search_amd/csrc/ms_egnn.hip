@@ -77,6 +77,24 @@ __device__ __forceinline__ float silu_f(float x) {
 }
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
+// Two / four SiLUs at a time: the same operations per element as silu_f (multiply by -log2(e), v_exp_f32, add 1,
+// v_rcp_f32, multiply), with the three non-transcendental ones as PACKED fp32 instructions (v_pk_mul_f32 /
+// v_pk_add_f32: one issue slot for two elements).  In the edge kernel every VALU instruction competes for issue
+// slots with the co-resident workgroup's MFMA chain (about 13 cycles each), so instruction count
+// is what matters there.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 silu2_f(f32x2 x) {
+    const f32x2 t = x * -1.4426950408889634f;
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(t.x);
+    e.y = __builtin_amdgcn_exp2f(t.y);
+    const f32x2 d = e + 1.0f;
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(d.x);
+    r.y = __builtin_amdgcn_rcpf(d.y);
+    return x * r;
+}
+
 // ---------------------------------------------------------------- weight preparation ---
 __global__ __launch_bounds__(256) void ms_egnn_prepare_kernel(const float *__restrict__ blob, float *__restrict__ prep) {
     const int layer = blockIdx.y;
@@ -307,11 +325,12 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 #pragma unroll
         for (int g = 0; g < STAGE_G; ++g) {
             const f32x4 wc = wc4[2 * (STAGE_G * s + g) + kh];
-            f32x4 hv;
-            hv.x = silu_f(fmaf(wc.x, d2, pa[g].x + pb[g].x));
-            hv.y = silu_f(fmaf(wc.y, d2, pa[g].y + pb[g].y));
-            hv.z = silu_f(fmaf(wc.z, d2, pa[g].z + pb[g].z));
-            hv.w = silu_f(fmaf(wc.w, d2, pa[g].w + pb[g].w));
+            const f32x4 zsum = pa[g] + pb[g];
+            const f32x2 d2v = {d2, d2};
+            const f32x2 z01 = __builtin_elementwise_fma(f32x2{wc.x, wc.y}, d2v, f32x2{zsum.x, zsum.y});
+            const f32x2 z23 = __builtin_elementwise_fma(f32x2{wc.z, wc.w}, d2v, f32x2{zsum.z, zsum.w});
+            const f32x2 h01 = silu2_f(z01), h23 = silu2_f(z23);
+            const f32x4 hv = {h01.x, h01.y, h23.x, h23.y};
             Hl[(g * 4 + (R >> 5)) * 64 + kh * 32 + (R & 31)] = hv;
         }
 #pragma unroll
@@ -353,23 +372,36 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         const float b2 = p.prep[P_B2 + 32 * nt + c];
         const float wg = p.prep[P_WG + 32 * nt + c];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float m = silu_f(acc[nt][r] + b2);          // edge_mlp[2] bias + SiLU (:21-22)
-            acc[nt][r] = m;
-            gate_dot[r] = fmaf(wg, m, gate_dot[r]);
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 m = silu2_f(f32x2{acc[nt][r], acc[nt][r + 1]} + b2);          // edge_mlp[2] bias + SiLU (:21-22)
+            acc[nt][r] = m.x;
+            acc[nt][r + 1] = m.y;
+            const f32x2 gd = __builtin_elementwise_fma(f32x2{wg, wg}, m, f32x2{gate_dot[r], gate_dot[r + 1]});
+            gate_dot[r] = gd.x;
+            gate_dot[r + 1] = gd.y;
         }
     }
     const float bg = p.prep[P_BG];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+        // sum over the 32 channel lanes of this half: cyclic doubling inside each row of 16 lanes with DPP rotations
+        // (row_ror 8, 4, 2, 1: no LDS crossbar), then the other row of the half
         float v = gate_dot[r];
-        v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xF, 0xF, false));
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xF, 0xF, false));
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xF, 0xF, false));
+        v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xF, 0xF, false));
+        v += __shfl_xor(v, 16);
         gate_dot[r] = sigmoid_f(v + bg);                      // edge_gate (:25-28)
     }
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] *= gate_dot[r];   // m_ij * gate (:64)
+        for (int r = 0; r < 16; r += 2) {                          // m_ij * gate (:64), two rows per instruction
+            const f32x2 mg = f32x2{acc[nt][r], acc[nt][r + 1]} * f32x2{gate_dot[r], gate_dot[r + 1]};
+            acc[nt][r] = mg.x;
+            acc[nt][r + 1] = mg.y;
+        }
 
     // per-residue partial sums over this wave's 32 consecutive edges (m_i = sum_j m_ij, :69)
     const int64_t u0 = e0 + 32 * wave;                 // first edge of the unit
@@ -386,14 +418,21 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
             const int hi = hi64 > 32 ? 32 : (int)hi64;
             const int q = unit - (int)(((int64_t)is * n) >> 5);
             float *dst = p.part + ((size_t)p.rec_pre[d] + (size_t)is * C + q) * MD;
+            // rows of this residue as 0/1 weights, once per residue; then 8 packed FMAs per channel tile
+            // (even and odd rows accumulate separately and are added last)
+            f32x2 wsel[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int row0 = (r & 3) + 8 * (r >> 2) + 4 * hh, row1 = ((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * hh;
+                wsel[r >> 1] = f32x2{(row0 >= lo && row0 < hi) ? 1.0f : 0.0f, (row1 >= lo && row1 < hi) ? 1.0f : 0.0f};
+            }
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
-                float sum = 0.0f;
+                f32x2 sum2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    sum += (row >= lo && row < hi) ? acc[nt][r] : 0.0f;
-                }
+                for (int r = 0; r < 16; r += 2)
+                    sum2 = __builtin_elementwise_fma(f32x2{acc[nt][r], acc[nt][r + 1]}, wsel[r >> 1], sum2);
+                float sum = sum2.x + sum2.y;
                 sum += __shfl_xor(sum, 32);
                 if (hh == 0) dst[32 * nt + c] = sum;
             }

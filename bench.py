@@ -30,6 +30,7 @@ One JSON line is printed by rank 0 (contract in the task statement), with
                 batch=1 EGNN loop; all on bounded samples;
   hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M, 4M and 45.6M rows: GB/s against the HBM peak;
   c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
+  k_sweep       (N = 1) the C2 shape at k = 1 / 10 / 20 / 32 / 64;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
                 peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
 `--no-extras` skips the last three, `--no-cpu-baseline` the CPU legs.
@@ -52,7 +53,7 @@ C4_NQ = 4096
 
 
 def scan_kernel_name(nq, k):
-    return "ms_scan_loader_kernel" if (nq > 64 and k <= 20) else "ms_scan_kernel"
+    return "ms_scan_loader_kernel" if (nq > 64 and k <= 32) else "ms_scan_kernel"
 
 
 def roofline(nq, rows, k, scan_ms, step_ms):
@@ -402,6 +403,16 @@ def main():
             line["hbm_regime"] += small
             del big, r4
             torch.cuda.empty_cache()
+        # list length: the same C2 shape at other k (k <= 10 / 20 / 32 run the loader-wave kernel with 5 / 10 / 16 list entries
+        # per lane, k <= 64 the non-loader kernel with 32)
+        line["k_sweep"] = []
+        for kk in (1, 10, 20, 32, 64):
+            bk = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, kk)
+            el, sc, _ = bk.run(40, 5, prep_budget_s=0.05)
+            line["k_sweep"].append({"k": kk, "ms_per_step": el / 40 * 1e3, "scan_ms": sc, "queries_per_s": nq * 40 / el,
+                                    "kernel": scan_kernel_name(nq, kk)})
+            log("k_sweep k=%d: %.3f ms per step (scan %.3f ms)" % (kk, el / 40 * 1e3, sc))
+            del bk
         line["embed"], extras_sd, extras_coords = embed_bench(torch, ops, log)
         bench.db, bench.q_raw = db_keep, q_keep
 

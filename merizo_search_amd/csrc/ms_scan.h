@@ -949,7 +949,8 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    if constexpr (KL <= 10 && !UB) {    // loader-wave form: short lists only (its compute waves must fit 256 registers)
+    if constexpr ((KL <= 10 || (KL == 16 && !AUX)) && !UB) {    // loader-wave form: its compute waves must fit 256 registers
+                                                                  // (16-entry lists only without the cosine-mode operands)
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
@@ -974,5 +975,6 @@ int launch_scan_kl(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 // One non-template entry point per list length (defined in ms_scan_kl*.hip).
 int ms_launch_scan_kl5(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
 int ms_launch_scan_kl10(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
+int ms_launch_scan_kl16(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
 int ms_launch_scan_kl32(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
 int ms_launch_scan_kl32ub(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);

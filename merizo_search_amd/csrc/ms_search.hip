@@ -373,10 +373,10 @@ int prepass_tiles_setting() {
     return v;
 }
 
-// list entries per lane and pass: 5 for k <= 10, 10 for k <= 20, else 32 (k <= 64)
+// list entries per lane and pass: 5 for k <= 10, 10 for k <= 20, 16 for k <= 32, else 32 (k <= 64)
 int pick_kl(int k_pass) {
-    const int opts[3] = {5, 10, 32};
-    for (int i = 0; i < 3; ++i)
+    const int opts[4] = {5, 10, 16, 32};
+    for (int i = 0; i < 4; ++i)
         if (2 * opts[i] >= k_pass) return opts[i];
     return 32;
 }
@@ -451,6 +451,7 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     if (sp.ub_s != nullptr) return ms_launch_scan_kl32ub(pl, sp, st);
     if (pick_kl(sp.k) == 5) return ms_launch_scan_kl5(pl, sp, st);
     if (pick_kl(sp.k) == 10) return ms_launch_scan_kl10(pl, sp, st);
+    if (pick_kl(sp.k) == 16) return ms_launch_scan_kl16(pl, sp, st);
     return ms_launch_scan_kl32(pl, sp, st);
 }
 

@@ -92,7 +92,9 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
 
 /* Merge S sorted result lists per query into the best k: faiss.ResultHeap(nq,k).add_result /
  * finalize (dbsearch.py:224,240,245) and the cross-shard merge after the RCCL all-gather.
- * scores float32 [S,nq,k], idx int64 [S,nq,k] (idx < 0 = padding), each list sorted best-first. */
+ * scores float32 [S,nq,k], idx int64 [S,nq,k] (idx < 0 = padding), each list sorted best-first
+ * (score descending, index ascending); an index appears in at most one list (shards / blocks are
+ * disjoint row ranges).  Any S >= 1. */
 int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k, float *out_scores,
                   int64_t *out_idx, ms_stream_t stream);
 

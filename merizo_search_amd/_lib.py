@@ -97,14 +97,22 @@ def check(rc: int, what: str) -> None:
         raise MerizoHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+_gpu_torch = None
+
+
 def require_gpu():
-    """Return the torch module after verifying a HIP device and the library are present."""
+    """Return the torch module after verifying a HIP device and the library are present (checked once per process:
+    every ops entry point calls this)."""
+    global _gpu_torch
+    if _gpu_torch is not None:
+        return _gpu_torch
     import torch
 
     lib = load()
     if not torch.cuda.is_available() or lib.ms_device_count() < 1:
         raise MerizoHipError("no MI355X / HIP device visible: the merizo_search_amd hot path runs on the GPU only "
                              "(use the reference implementation for CPU runs)")
+    _gpu_torch = torch
     return torch
 
 

@@ -363,3 +363,23 @@ def test_nan_and_inf_rows_are_never_returned(torch_gpu):
         keep = np.setdiff1d(np.arange(n), bad)
         s_ref, i_ref = orc.ip_topk(db[keep], q, 10, order=1)
         assert np.array_equal(i, keep[i_ref]) and np.array_equal(s.view(np.uint32), s_ref.view(np.uint32))
+
+
+def test_empty_shard_is_searchable(torch_gpu):
+    """A rank of a sharded search may hold no rows at all (more ranks than rows): both modes return (-inf, -1) lists that
+    the merge then ignores."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    q = _dev(torch, _norm_db(5, seed=2))
+    empty = torch.empty((0, 128), dtype=torch.float32, device="cuda")
+    for nq in (1, 5):
+        s, i = ops.ip_topk(empty, q[:nq], 3, row_offset=77)
+        assert np.isneginf(s.cpu().numpy()).all() and (i.cpu().numpy() == -1).all()
+        s, i = ops.ip_topk(empty, q[:nq], 3, mode=ops.MODE_COSINE_RAW, inv_norm=ops.row_inv_norms(empty),
+                           lengths=torch.empty(0, device="cuda"), qlen=torch.ones(nq, device="cuda"), mincov=0.7)
+        assert np.isneginf(s.cpu().numpy()).all() and (i.cpu().numpy() == -1).all()
+    db = _dev(torch, _norm_db(100, seed=3))
+    full = ops.ip_topk(db, q, 3)
+    e = ops.ip_topk(empty, q, 3, row_offset=100)
+    ms, mi = ops.topk_merge(torch.stack([full[0], e[0]]), torch.stack([full[1], e[1]]))
+    assert torch.equal(ms, full[0]) and torch.equal(mi, full[1])

@@ -1,5 +1,5 @@
 // Scan kernels of the search path and their launch templates, shared by the translation units that
-// instantiate them (one per list length, so that they compile in parallel): ms_scan_kl5.hip,
+// instantiate them (one per list length, so that they compile in parallel): ms_scan_kl5.hip, ms_scan_kl16.hip,
 // ms_scan_kl10.hip, ms_scan_kl32.hip, ms_scan_kl32ub.hip.  ms_search.hip holds everything else.
 #pragma once
 #include "ms_common.h"

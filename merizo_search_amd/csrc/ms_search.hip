@@ -443,7 +443,8 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     if (mode != MS_MODE_IP_PRENORM && mode != MS_MODE_COSINE_RAW) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: unknown mode %d", mode);
     if (mode == MS_MODE_IP_PRENORM && (inv_norm || lengths || qlen))
         MS_FAIL(MS_ERR_ARG, "ms_ip_topk: inv_norm / lengths / qlen are only valid in MS_MODE_COSINE_RAW");
-    if ((lengths == nullptr) != (qlen == nullptr)) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: lengths and qlen go together");
+    // (an empty shard -- a rank of a sharded search with no rows -- has NULL row arrays)
+    if (n > 0 && (lengths == nullptr) != (qlen == nullptr)) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: lengths and qlen go together");
     return MS_OK;
 }
 

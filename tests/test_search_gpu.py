@@ -383,3 +383,20 @@ def test_empty_shard_is_searchable(torch_gpu):
     e = ops.ip_topk(empty, q, 3, row_offset=100)
     ms, mi = ops.topk_merge(torch.stack([full[0], e[0]]), torch.stack([full[1], e[1]]))
     assert torch.equal(ms, full[0]) and torch.equal(mi, full[1])
+
+
+@pytest.mark.parametrize("n,nq,k", [(5000, 4, 100), (5000, 70, 130), (40_000, 3, 64), (300, 33, 300)])
+def test_cosine_mask_large_k_vs_reference_arithmetic(n, nq, k, torch_gpu):
+    """Cosine + length mask with k beyond one pass (k > 64: ceil(k / 64) scans with an exclusive upper bound) and k = n,
+    against the oracle's reference arithmetic."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    raw, lengths = syn.raw_database(n, seed=95 + n % 5)
+    rq, qlen = syn.raw_queries(nq, seed=96)
+    d = _dev(torch, raw)
+    s, i = ops.ip_topk(d, _dev(torch, rq), k, mode=ops.MODE_COSINE_RAW, inv_norm=ops.row_inv_norms(d),
+                       lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
+    s_ref, i_ref = orc.cosine_topk(raw, rq, k, lengths, qlen, 0.7)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)

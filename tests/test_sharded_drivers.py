@@ -20,7 +20,10 @@ def _make_case(work, n=3001, nq=7, k=10, batch=500):
     from merizo_search_amd.foldclass import dbutil, synthetic as syn
     os.makedirs(work, exist_ok=True)
     raw, lengths = syn.raw_database(n, seed=11)
-    raw[5] = raw[n - 3]; raw[n // 2 - 1] = raw[n // 2 + 4]; raw[7] = raw[8]
+    if n > 20:
+        raw[5] = raw[n - 3]; raw[n // 2 - 1] = raw[n // 2 + 4]; raw[7] = raw[8]
+    else:
+        lengths[:] = 30.0                                      # tiny databases: nothing masked, k <= n stays valid
     names = ["d%06d" % i for i in range(n)]
     seqs = ["A" * int(l) for l in lengths]
     coords = [np.zeros((int(l), 3), np.float32) for l in lengths]
@@ -129,6 +132,18 @@ def test_run_dbsearch_sharded_equals_one_rank_hip_engine_two_ranks(tmp_path):
     _run_ranks(work, 1, "hip")
     _run_ranks(work, 2, "hip")
     _compare(work, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,nq,k,world", [(3, 1, 2, 2), (1, 2, 1, 2), (5, 3, 5, 3)])
+def test_run_dbsearch_sharded_tiny_databases_hip_engine(n, nq, k, world, tmp_path):
+    """Shards smaller than k, and ranks with no rows at all (more ranks than rows): padded / empty per-shard lists go
+    through the all-gather and the merge; same TSV and score bits as one rank."""
+    work = str(tmp_path / "case")
+    _make_case(work, n=n, nq=nq, k=k, batch=2)
+    _run_ranks(work, 1, "hip")
+    _run_ranks(work, world, "hip")
+    _compare(work, world)
 
 
 @pytest.mark.gpu

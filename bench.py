@@ -31,6 +31,7 @@ One JSON line is printed by rank 0 (contract in the task statement), with
   hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M, 4M and 45.6M rows: GB/s against the HBM peak;
   c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
   k_sweep       (N = 1) the C2 shape at k = 1 / 10 / 20 / 32 / 64;
+  c3_search     (N = 1) C3's search half: 500k RAW rows, 1000 queries, cosine + length mask;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
                 peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
 `--no-extras` skips the last three, `--no-cpu-baseline` the CPU legs.
@@ -196,6 +197,55 @@ def hbm_regime(make, rows_list, log):
                         "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k)})
             log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s), step %.3f ms" % (rows, nq, scan_ms, out[-1]["scan_frac_of_hbm_peak"] * 100, ms))
             del b
+    return out
+
+
+def c3_search_bench(torch, ops, syn, dev, k, log):
+    """C3's search half: a `.pt`-style database of 500,000 RAW rows, 1000 query embeddings, cosine + length mask
+    (search_query_against_db, dbsearch.py:75-81; mincov 0.7), row norms cached once per database."""
+    n, nq, mincov = 500_000, 1000, 0.7
+    db = syn.device_database(n, 0, seed=3, device=dev, normalize=False) * 2.5
+    lengths = torch.from_numpy(syn.ted_lengths(n, seed=4).astype(np.float32)).to(dev)
+    qlen = torch.from_numpy(syn.ted_lengths(nq, seed=5).astype(np.float32)).to(dev)
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    q = torch.randn((nq, 128), generator=g, device=dev, dtype=torch.float32)
+    inv = ops.row_inv_norms(db)
+    ws = torch.empty_like(ops.TopKWorkspace(dev).get(n, nq, k))
+    out_s = torch.empty((nq, k), dtype=torch.float32, device=dev)
+    out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    kw = dict(mode=ops.MODE_COSINE_RAW, inv_norm=inv, lengths=lengths, qlen=qlen, mincov=mincov)
+
+    def step(ev=None):
+        ops.ip_topk_prepare(db, q, k, ws, **kw)
+        if ev is not None:
+            ev[0].record()
+        ops.ip_topk_scan(db, q, k, ws, **kw)
+        if ev is not None:
+            ev[1].record()
+        ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    steps = 40
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t = time.perf_counter()
+    for s_ in range(steps):
+        step(evs[s_])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / steps * 1e3
+    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    # check: masked cosine of the returned rows, recomputed in float64, and order
+    rows = db[out_i.reshape(-1)].double().reshape(nq, k, 128)
+    cos = (rows * q.double()[:, None, :]).sum(2) / rows.norm(dim=2) / q.double().norm(dim=1)[:, None]
+    cos = cos * (qlen[:, None] >= lengths[out_i] * mincov).double()
+    err = float((cos - out_s.double()).abs().max())
+    out = {"workload": "C3 search half: 500,000 x 128 RAW fp32 rows (.pt layout), 1000 queries, cosine + length mask (mincov 0.7), top-%d" % k,
+           "ms_per_step": ms, "queries_per_s": nq / ms * 1e3, "max_abs_score_error_vs_float64": err,
+           "roofline": roofline(nq, n, k, scan_ms, ms)}
+    out["roofline"]["kernel"] = "ms_scan_loader_kernel (cosine variant: row scales and lengths through a 17th LDS-DMA piece per tile)"
+    log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
+    del db, lengths, inv, ws
     return out
 
 
@@ -413,6 +463,7 @@ def main():
                                     "kernel": scan_kernel_name(nq, kk)})
             log("k_sweep k=%d: %.3f ms per step (scan %.3f ms)" % (kk, el / 40 * 1e3, sc))
             del bk
+        line["c3_search"] = c3_search_bench(torch, ops, syn, dev, k, log)
         line["embed"], extras_sd, extras_coords = embed_bench(torch, ops, log)
         bench.db, bench.q_raw = db_keep, q_keep
 

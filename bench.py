@@ -7,7 +7,7 @@
 
 N = 1 (default): BASELINE.json configs[1] (C2) -- brute-force cosine top-10 over a 1M x 128 float32
 synthetic database, batch = 256 queries.  A step is one pass of the hot path over one query batch:
-raw query embeddings -> ms_l2_normalize_rows -> sample pass -> fused Q.D^T + top-k scan of the
+raw query embeddings -> ms_l2_normalize_rows_to -> sample pass -> fused Q.D^T + top-k scan of the
 resident shard -> merge of the per-stream lists [-> RCCL all-gather of the per-shard top-k + shard
 merge when N > 1].  The database and the raw query embeddings are resident in HBM before the timed
 region starts.
@@ -103,8 +103,7 @@ class SearchBench:
 
     def step(self, events=None):
         ops, ex = self.ops, self.ex
-        self.q.copy_(self.q_raw)                                            # the batch's raw embeddings (what the encoder hands over)
-        ops.l2_normalize_rows_(self.q, 1e-12)                               # F.normalize (dbsearch.py:303-304)
+        ops.l2_normalize_rows(self.q_raw, 1e-12, out=self.q)                # F.normalize of the batch's raw embeddings (dbsearch.py:303-304)
         ops.ip_topk_prepare(self.db, self.q, self.k, self.ws)               # sample pass (lower bound per query)
         if events is not None:
             events[0].record()

@@ -48,6 +48,9 @@ int ms_device_cu_count(void);
 /* F.normalize(x) in place: x[r,:] /= max(||x[r,:]||_2, eps).  dbsearch.py:303-304 (eps 1e-12);
  * also the per-operand normalisation inside F.cosine_similarity (eps 1e-8), dbsearch.py:78. */
 int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stream);
+/* The same, out of place (what F.normalize itself does): y[r,:] = x[r,:] / max(||x[r,:]||_2, eps); x is not
+ * modified, y may not overlap x.  Bit-identical to ms_l2_normalize_rows on a copy. */
+int ms_l2_normalize_rows_to(const float *x, float *y, int64_t n, int d, float eps, ms_stream_t stream);
 
 /* inv_norm[r] = 1 / max(||x[r,:]||_2, eps): the database half of F.cosine_similarity
  * (dbsearch.py:78), computed once per database instead of once per query. */

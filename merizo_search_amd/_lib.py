@@ -38,6 +38,7 @@ SIGNATURES = {
     "ms_device_count": (_int, []),
     "ms_device_cu_count": (_int, []),
     "ms_l2_normalize_rows": (_int, [_vp, _i64, _int, _f, _vp]),
+    "ms_l2_normalize_rows_to": (_int, [_vp, _vp, _i64, _int, _f, _vp]),
     "ms_row_inv_norms": (_int, [_vp, _i64, _int, _f, _vp, _vp]),
     "ms_ip_topk_workspace_bytes": (_sz, [_i64, _int, _int]),
     "ms_ip_topk": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _vp, _vp, _sz, _vp]),

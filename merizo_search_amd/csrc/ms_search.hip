@@ -40,18 +40,17 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void ms_normalize_rows_kernel(float *x, int64_t n, float eps) {
+__global__ __launch_bounds__(256) void ms_normalize_rows_kernel(const float *x, float *y, int64_t n, float eps) {   // y may be x
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * 4;
     for (int64_t r = wave0; r < n; r += nwaves) {
-        float2 *p = reinterpret_cast<float2 *>(x + r * MS_DIM) + lane;
-        float2 v = *p;
+        float2 v = *(reinterpret_cast<const float2 *>(x + r * MS_DIM) + lane);
         const float ss = wave_sum(v.x * v.x + v.y * v.y);
         const float nrm = fmaxf(sqrtf(ss), eps);
         v.x = v.x / nrm;
         v.y = v.y / nrm;
-        *p = v;
+        *(reinterpret_cast<float2 *>(y + r * MS_DIM) + lane) = v;
     }
 }
 
@@ -586,7 +585,18 @@ int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stre
     if (n == 0) return MS_OK;
     const int64_t blocks = (n + 3) / 4;
     hipLaunchKernelGGL(ms_normalize_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
-                       (hipStream_t)stream, x, n, eps);
+                       (hipStream_t)stream, x, x, n, eps);
+    MS_LAUNCH_CHECK("ms_normalize_rows_kernel");
+    return MS_OK;
+}
+
+int ms_l2_normalize_rows_to(const float *x, float *y, int64_t n, int d, float eps, ms_stream_t stream) {
+    if (d != MS_DIM) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows_to: d must be %d (got %d)", MS_DIM, d);
+    if (n < 0 || (n > 0 && (x == nullptr || y == nullptr))) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows_to: bad arguments");
+    if (n == 0) return MS_OK;
+    const int64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(ms_normalize_rows_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, n, eps);
     MS_LAUNCH_CHECK("ms_normalize_rows_kernel");
     return MS_OK;
 }

@@ -322,7 +322,7 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
 
     query_dicts = _load_queries(queries, inputs_are_ca, _chain_list(pdb_chain, nq))
     emb = sharded.embed_distributed(network, [qd["coords"] for qd in query_dicts])   # ragged launches, data-parallel over ranks
-    emb = engine.normalize_(emb.clone() if hasattr(emb, "clone") else emb, 1e-12)   # F.normalize (:303-304)
+    emb = engine.normalized(emb, 1e-12)                                     # F.normalize (:303-304): one launch, out of place
 
     # this rank's rows of the matrix: [lo, hi) of DB_SIZE (all of them on one rank)
     rank, world = sharded.rank_world()

@@ -10,6 +10,7 @@ Engine interface (tensors are torch tensors on the engine's device):
     embed(list of float32 [N,3] arrays)                     -> float32 [B,128]
     to_device(numpy array)                                  -> tensor
     normalize_(x, eps)                                      -> x, rows L2-normalised in place
+    normalized(x, eps)                                      -> new tensor, rows L2-normalised (F.normalize)
     row_inv_norms(db, eps)                                  -> float32 [n]
     cosine_topk(db, q, k, inv_norm, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
     ip_topk(db, q, k, row_offset)                           -> (scores [nq,k], idx int64 [nq,k])
@@ -88,6 +89,9 @@ class HipEngine:
 
     def normalize_(self, x, eps: float = 1e-12):
         return self._ops.l2_normalize_rows_(x, eps)
+
+    def normalized(self, x, eps: float = 1e-12):
+        return self._ops.l2_normalize_rows(x, eps)
 
     def row_inv_norms(self, db, eps: float = 1e-8):
         return self._ops.row_inv_norms(db, eps)

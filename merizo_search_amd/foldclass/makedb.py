@@ -67,7 +67,7 @@ def run_createdb(pdb_files: str, out_db: str, device: str = "cuda", network=None
         logging.info(f"Saved Foldclass database to {out_db}.pt")
         logging.info(f"Saved Foldclass index file to {out_db}.index")
     if layout in ("faiss", "both"):
-        normed = network.engine.normalize_(emb.clone(), 1e-12).cpu().numpy()
+        normed = network.engine.normalized(emb, 1e-12).cpu().numpy()
         short = _faiss_layout_names(names)
         write_faiss_db(out_db, normed, short, seqs, coords)
         logging.info(f"Saved faiss-layout database to {out_db}.json")

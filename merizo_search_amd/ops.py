@@ -58,6 +58,18 @@ def l2_normalize_rows_(x, eps: float = 1e-12):
     return x
 
 
+def l2_normalize_rows(x, eps: float = 1e-12, out=None):
+    """F.normalize(x) out of place (reference dbsearch.py:303-304) -> a new tensor, or `out`."""
+    torch = _lib.require_gpu()
+    _f32_cuda(x, "x", DIM)
+    y = torch.empty_like(x) if out is None else _f32_cuda(out, "out", DIM)
+    if y.shape != x.shape or y.data_ptr() == x.data_ptr():
+        raise MerizoHipError("l2_normalize_rows: out must have x's shape and not alias it")
+    with _on(x, y) as dev:
+        check(_lib.load().ms_l2_normalize_rows_to(ptr(x), ptr(y), x.shape[0], DIM, eps, dev.stream), "ms_l2_normalize_rows_to")
+    return y
+
+
 def row_inv_norms(x, eps: float = 1e-8):
     """1 / max(||row||, eps) for every database row (the DB half of cosine_similarity)."""
     torch = _lib.require_gpu()

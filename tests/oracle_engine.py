@@ -36,6 +36,9 @@ class OracleEngine:
         x.copy_(torch.from_numpy(orc.l2_normalize_rows(x.numpy(), eps)))
         return x
 
+    def normalized(self, x, eps=1e-12):
+        return torch.from_numpy(orc.l2_normalize_rows(x.numpy(), eps))
+
     def row_inv_norms(self, db, eps=1e-8):
         n = np.sqrt((db.numpy().astype(np.float32) ** 2).sum(1, dtype=np.float32))
         return torch.from_numpy((1.0 / np.maximum(n, eps)).astype(np.float32))

@@ -158,6 +158,9 @@ def test_normalize_rows_matches_reference_golden(torch_gpu, golden_dir):
     y = ops.l2_normalize_rows_(_dev(torch, g["x"].copy()), 1e-12).cpu().numpy()
     np.testing.assert_allclose(y, g["y12"], rtol=5e-7, atol=0)
     assert (y[3] == 0).all()
+    x_dev = _dev(torch, g["x"].copy())
+    y2 = ops.l2_normalize_rows(x_dev, 1e-12)                    # out of place: same bits, input untouched
+    assert np.array_equal(y2.cpu().numpy().view(np.uint32), y.view(np.uint32)) and np.array_equal(x_dev.cpu().numpy(), g["x"])
     inv = ops.row_inv_norms(_dev(torch, g["x"]), 1e-8).cpu().numpy()
     nrm = np.maximum(np.sqrt((g["x"].astype(np.float64) ** 2).sum(1)), 1e-8)
     np.testing.assert_allclose(inv, 1.0 / nrm, rtol=5e-7)

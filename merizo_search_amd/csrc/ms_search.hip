@@ -267,6 +267,44 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
     }
 }
 
+// ------------------------------------------------------------------ sample bound -------
+// Lower bound of the full pass from the sample pass's lists: the k-th largest (with multiplicity) of the first
+// `ranks` entries of all P lists of a query -- scores of distinct rows, so at least k rows score >= the result.
+// Values only (no rows, no sorted output): one wave per query, the values in registers, k rounds of "largest value
+// below the previous one + how many lanes hold it".  -inf when there are fewer than k sampled rows.
+template <int VPL>      // values per lane: ranks * P <= 64 * VPL
+__global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float *ps = part_s + (size_t)q * k * P;              // rank-major [k][P]: the first ranks * P floats
+    const int count = ranks * P;
+    float v[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int idx = lane + 64 * i;
+        v[i] = idx < count ? ps[idx] : -INFINITY;
+    }
+    float cur = INFINITY, kth = -INFINITY;
+    int remaining = k;
+    for (int round = 0; round < k; ++round) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) m = (v[i] < cur) ? fmaxf(m, v[i]) : m;
+        // wave maximum: 4 DPP steps inside each row of 16 lanes, then the 4 row results through SGPRs
+#define MS_DPP_FMAX(CTRL) m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(m), CTRL, 0xF, 0xF, false)));
+        MS_DPP_FMAX(0xB1) MS_DPP_FMAX(0x4E) MS_DPP_FMAX(0x141) MS_DPP_FMAX(0x140)
+#undef MS_DPP_FMAX
+        m = fmaxf(fmaxf(ms_readlane_f(m, 0), ms_readlane_f(m, 16)), fmaxf(ms_readlane_f(m, 32), ms_readlane_f(m, 48)));
+        if (!(m > -INFINITY)) break;                              // fewer than k values: no bound
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) c += __popcll(__ballot(v[i] == m));
+        if (c >= remaining) { kth = m; break; }
+        remaining -= c;
+        cur = m;
+    }
+    if (lane == 0) lb[q] = kth;
+}
+
 // ------------------------------------------------------------------ public k-way merge -
 // One thread per query: classic k-way merge of S lists that are each sorted best-first.
 __global__ __launch_bounds__(64) void ms_kway_merge_kernel(const float *scores0, const int64_t *idx0, int64_t score_stride,
@@ -534,11 +572,25 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     int rc = launch_scan(pl, s0, st);
     if (rc) return rc;
     float *lb = reinterpret_cast<float *>(ws + pl.off_lb_s);
-    float *scratch_s = reinterpret_cast<float *>(ws + pl.off_scr_s);
-    int64_t *scratch_i = reinterpret_cast<int64_t *>(ws + pl.off_scr_i);
-    uint32_t *lb_i = reinterpret_cast<uint32_t *>(ws + pl.off_lb_i);
-    rc = launch_merge(pl, s0, nq, s0.k, 0, scratch_s, scratch_i, s0.k, 0, lb, lb_i, st);
-    if (rc) return rc;
+    // the sample kernel leaves at most 2 entries per (query, stream) and merges the 4 / qwb streams of a workgroup: only the
+    // first `ranks` entries of a list can be valid.  Their k-th largest value is the bound: no rows, no sorted list needed.
+    const int ranks = (2 * (4 / pl.qwb) < s0.k) ? 2 * (4 / pl.qwb) : s0.k;
+    const int vpl = (ranks * pl.P + 63) / 64;
+    if (vpl <= 32) {
+#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb)
+        if (vpl <= 4) { MS_BOUND(4); }
+        else if (vpl <= 8) { MS_BOUND(8); }
+        else if (vpl <= 16) { MS_BOUND(16); }
+        else { MS_BOUND(32); }
+#undef MS_BOUND
+        MS_LAUNCH_CHECK("ms_sample_bound_kernel");
+    } else {
+        float *scratch_s = reinterpret_cast<float *>(ws + pl.off_scr_s);
+        int64_t *scratch_i = reinterpret_cast<int64_t *>(ws + pl.off_scr_i);
+        uint32_t *lb_i = reinterpret_cast<uint32_t *>(ws + pl.off_lb_i);
+        rc = launch_merge(pl, s0, nq, s0.k, 0, scratch_s, scratch_i, s0.k, 0, lb, lb_i, st);
+        if (rc) return rc;
+    }
     sp->lb_s = lb;
     return MS_OK;
 }

@@ -322,6 +322,19 @@ def cpu_baseline(db, q_unit, k, n_total, sd, embed_coords):
     torch_legs = tb.time_search_legs(db[:rows_t].cpu().numpy(), qh, k, n_total)
     if sd is not None:
         torch_legs["egnn_batch1_loop"] = tb.time_egnn_leg(sd, embed_coords[:200], budget_s=10.0)
+        # the C restatement of the encoder (oracle.c:orc_egnn_embed, OpenMP over edge rows) on the first structures of the same set
+        from merizo_search_amd.foldclass import weights as W
+        w, pe = W.pack_state_dict(sd)
+        done, t0e = [], time.perf_counter()
+        for c in embed_coords[:200]:
+            orc.egnn_embed(w, pe, [c])
+            done.append(len(c) ** 2)
+            if time.perf_counter() - t0e > 5.0:
+                break
+        dte = time.perf_counter() - t0e
+        total_sq = float(sum(len(c) ** 2 for c in embed_coords))
+        out["oracle_egnn"] = {"embeds_per_s": len(embed_coords) / (dte * total_sq / float(sum(done))), "cores": cores, "kind": "port",
+                              "sample": "%d of %d structures, %.2f s, scaled by sum N^2" % (len(done), len(embed_coords), dte)}
     out["torch_cpu"] = torch_legs
     return out
 

@@ -96,6 +96,7 @@ def time_search_legs(db_unit: np.ndarray, q_unit: np.ndarray, k: int, n_total: i
     nq1 = min(q.shape[0], 4)
     out["pt_path_per_query"] = leg(lambda: pt_path_search(db, lengths, q[:nq1], [100.0] * nq1, 0.7, k), nq1)
     out["faiss_path_blockwise_262144"] = leg(lambda: faiss_path_search(db, q, k), q.shape[0])
+    out["faiss_path_blockwise_262144_nq1"] = leg(lambda: [faiss_path_search(db, q[j:j + 1], k) for j in range(nq1)], nq1)
     threads = torch.get_num_threads()
     torch.set_num_threads(1)
     try:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Foldclass search benchmark: queries/sec of the exact 128-d cosine top-k scan on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: starts its own ranks as children)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -353,6 +353,20 @@ def main():
                     help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without an outer launcher: start the N ranks as a FRESH child process tree
+        # (torch.distributed.run, one rank per GPU) before anything in this process has touched the GPU, pass its
+        # output through and exit with its code.  Nothing is exec'd; this parent never initialises HIP.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        raise SystemExit(subprocess.call(cmd))
+
     import torch
     import torch.distributed as dist
 
@@ -360,7 +374,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
 
     from merizo_search_amd import _lib, ops
     from merizo_search_amd.foldclass import sharded, synthetic as syn
@@ -368,12 +382,15 @@ def main():
     _lib.require_gpu()                                   # fails loudly without the HIP library / a GPU
     # self-test hooks (one-GPU boxes): MS_BENCH_SAME_DEVICE=1 puts every rank on cuda:0 and
     # MS_BENCH_BACKEND=gloo swaps the collective backend, so that the multi-rank logic can be run end to end
-    dev_index = 0 if os.environ.get("MS_BENCH_SAME_DEVICE") == "1" else local_rank
+    same_device = os.environ.get("MS_BENCH_SAME_DEVICE") == "1"
+    backend = os.environ.get("MS_BENCH_BACKEND", "nccl")                 # "nccl" is RCCL on ROCm
+    if world > 1 and same_device and backend == "nccl":
+        raise SystemExit("MS_BENCH_SAME_DEVICE=1 puts every rank on cuda:0, which RCCL cannot do: set MS_BENCH_BACKEND=gloo")
+    dev_index = 0 if same_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MS_BENCH_BACKEND", "nccl")             # "nccl" is RCCL on ROCm
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:

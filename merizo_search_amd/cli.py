@@ -66,6 +66,43 @@ def _add_search_flags(p: argparse.ArgumentParser, default_format: str) -> None:
     p.add_argument("--weights", type=str, default=None, help="Path to FINAL_foldclass_model.pt.")
 
 
+# The reference's easy-search also takes the Merizo segmenter's options (merizo.py:262-286).  The segmenter is out of scope
+# here (the chopping is an input), but a reference command line must still parse: every one of them is accepted with the
+# reference's type and default, and reported as ignored when the user set it.
+_SEGMENTER_FLAGS = (
+    ("--merizo_output", dict(type=str, default=os.environ.get("PWD", "."))),
+    ("--save_pdf", dict(action="store_true", default=False)),
+    ("--save_pdb", dict(action="store_true", default=False)),
+    ("--save_domains", dict(action="store_true", default=False)),
+    ("--save_fasta", dict(action="store_true", default=False)),
+    ("--conf_filter", dict(type=float, default=None)),
+    ("--plddt_filter", dict(type=float, default=None)),
+    ("--iterate", dict(action="store_true", default=False)),
+    ("--length_conditional_iterate", dict(action="store_true", default=False)),
+    ("--max_iterations", dict(type=int, default=3)),
+    ("--shuffle_indices", dict(action="store_true", default=False)),
+    ("--return_indices", dict(action="store_true", default=False)),
+    ("--min_domain_size", dict(type=int, default=50)),
+    ("--min_fragment_size", dict(type=int, default=10)),
+    ("--domain_ave_size", dict(type=int, default=200)),
+    ("--conf_threshold", dict(type=float, default=0.5)),
+)
+
+
+def _add_segmenter_flags(p: argparse.ArgumentParser) -> None:
+    g = p.add_argument_group("Merizo segmenter options (accepted for command-line compatibility with the reference, ignored: "
+                             "the chopping is an input of this build)")
+    for flag, kw in _SEGMENTER_FLAGS:
+        g.add_argument(flag, help="Ignored.", **kw)
+
+
+def _warn_ignored_segmenter_flags(args) -> None:
+    given = [flag for flag, kw in _SEGMENTER_FLAGS if getattr(args, flag[2:]) != kw["default"]]
+    if given:
+        logging.warning("Ignoring the Merizo segmenter option(s) %s: the segmenter is not part of this build, domains come "
+                        "from --chopping / --segment_tsv." % ", ".join(given))
+
+
 def _join_process_group(args) -> None:
     """Under torchrun (WORLD_SIZE > 1): join the process group before the first GPU call and pin this
     rank to its GPU; ranks other than 0 log warnings only."""
@@ -164,7 +201,9 @@ def easy_search(argv) -> None:
                    help="Domain chopping of the corresponding input, reference syntax e.g. '71-189,190-290,291-453' "
                         "(repeat the flag once per input).")
     p.add_argument("--segment_tsv", type=str, default=None, help="A reference `_segment.tsv` to take the choppings from.")
+    _add_segmenter_flags(p)
     args = p.parse_args(argv)
+    _warn_ignored_segmenter_flags(args)
     _join_process_group(args)
     tmp = munge_tmp_with_uuid(args.tmp)
     _log_command("easy-search")

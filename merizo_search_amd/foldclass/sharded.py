@@ -26,6 +26,19 @@ import numpy as np
 
 BACKEND_ENV = "MERIZO_DIST_BACKEND"          # "nccl" (= RCCL, default) | "gloo" (self-tests on a one-GPU box)
 SAME_DEVICE_ENV = "MERIZO_SAME_DEVICE"       # "1": every rank uses cuda:0 (self-tests on a one-GPU box; gloo only)
+TIMEOUT_ENV = "MERIZO_DIST_TIMEOUT_S"        # collective timeout of the process group in seconds (default: one day)
+FINISH_TIMEOUT_ENV = "MERIZO_FINISH_TIMEOUT_S"   # how long ranks != 0 wait for rank 0's post-processing (default: 30 days)
+_FINISH_KEY, _ACK_KEY = "merizo_search_amd/finished", "merizo_search_amd/acks"
+
+
+def _env_seconds(name: str, default: float):
+    from datetime import timedelta
+
+    try:
+        v = float(os.environ.get(name, default))
+    except ValueError:
+        v = default
+    return timedelta(seconds=max(v, 1.0))
 
 
 def rank_world(group=None) -> Tuple[int, int]:
@@ -55,25 +68,60 @@ def init_distributed() -> Tuple[int, int, Optional[str]]:
     else:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
-    index = 0 if os.environ.get(SAME_DEVICE_ENV) == "1" else local
+    same_device = os.environ.get(SAME_DEVICE_ENV) == "1"
+    backend = os.environ.get(BACKEND_ENV, "nccl")
+    if same_device and backend == "nccl" and not dist.is_initialized():
+        # RCCL needs one GPU per rank: ranks that share a device fail or hang inside the communicator set-up
+        raise RuntimeError(f"{SAME_DEVICE_ENV}=1 puts every rank on cuda:0, which the nccl (RCCL) backend cannot do: "
+                           f"set {BACKEND_ENV}=gloo for one-GPU self-tests")
+    index = 0 if same_device else local
     device = torch.device("cuda", index)
     if torch.cuda.is_available():          # (without a GPU the engine set-up that follows fails loudly)
         torch.cuda.set_device(device)
     if not dist.is_initialized():
-        backend = os.environ.get(BACKEND_ENV, "nccl")
+        # Collectives here are short (a few hundred KB per batch), but rank 0's serial post-processing (TM-align per hit,
+        # the multi-domain step, the TSV files) is not: the other ranks must never sit in a device collective with the
+        # default 10-minute watchdog while it runs (finalize_distributed waits on the store instead), and the group's own
+        # timeout is generous.
+        timeout = _env_seconds(TIMEOUT_ENV, 86400.0)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)
+            dist.init_process_group("nccl", device_id=device, timeout=timeout)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=timeout)
     return dist.get_rank(), dist.get_world_size(), f"cuda:{index}"
 
 
 def finalize_distributed() -> None:
+    """End of a multi-rank run.  Ranks other than 0 return from the drivers right after the exchange, while rank 0 still
+    runs its serial post-processing, possibly for hours.  They therefore do NOT wait in a collective (a pending RCCL
+    barrier keeps their GPUs spinning and trips the watchdog after the group's timeout): rank 0 sets a key in the process
+    group's store when it is done, the others block on that key (a host-side socket wait), acknowledge, and everybody
+    tears the group down; rank 0 waits for the acknowledgements so that the store outlives its readers."""
+    import time
+
     import torch.distributed as dist
 
-    if dist.is_available() and dist.is_initialized():
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    store = None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+    except Exception:                       # (private accessor: fall back to a collective if a torch release drops it)
+        store = None
+    if world > 1 and store is not None:
+        limit = _env_seconds(FINISH_TIMEOUT_ENV, 30 * 86400.0)
+        if rank == 0:
+            store.set(_FINISH_KEY, "1")
+            t0 = time.monotonic()
+            while int(store.add(_ACK_KEY, 0)) < world - 1 and time.monotonic() - t0 < 600.0:
+                time.sleep(0.01)
+        else:
+            store.wait([_FINISH_KEY], limit)
+            store.add(_ACK_KEY, 1)
+    elif world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    dist.destroy_process_group()
 
 
 def shard_bounds(n_total: int, world: int, rank: int) -> Tuple[int, int]:

@@ -153,3 +153,20 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     rc = lib.ms_egnn_embed(ctypes.c_void_p(16), ctypes.c_void_p(16), 3000, ctypes.c_void_p(16), ctypes.c_void_p(16),
                            offs.ctypes.data, 1, ctypes.c_void_p(16), None, 0, None)
     assert rc == -4 and b"positional table" in lib.ms_last_error()
+
+
+def test_bench_self_launches_its_ranks_without_a_gpu_call_in_the_parent(tmp_path):
+    """`python bench.py --gpus 2` with no outer launcher starts torch.distributed.run as a CHILD before importing torch
+    (never exec), passes the ranks' output through and exits with their code.  Here (no GPU) the ranks must fail loudly in
+    _lib.require_gpu(), and the parent must report that failure."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert "launching 2 ranks" in r.stderr
+    assert "--nproc-per-node=2" in r.stderr
+    import torch
+    if not torch.cuda.is_available():
+        assert r.returncode != 0                      # children ran and refused to run without a GPU: no silent fallback
+        assert "GPU" in r.stderr or "HIP" in r.stderr or "hip" in r.stderr

@@ -110,6 +110,45 @@ def test_cli_under_torchrun_two_ranks_gloo_oracle(tmp_path):
         assert a == b, suffix
 
 
+def test_ranks_wait_out_rank0_postprocessing_beyond_the_group_timeout(tmp_path):
+    """Rank 0's serial post-processing (TM-align per hit, multi-domain step, TSV files) may outlast the process group's
+    collective timeout: the other ranks wait on the store, not in a collective, so nobody is aborted.
+    Group timeout 2 s, rank 0 'post-processes' for 5 s."""
+    script = tmp_path / "slow_rank0.py"
+    script.write_text(r"""
+import os, sys, time
+sys.path.insert(0, sys.argv[1])
+import torch, torch.distributed as dist
+from merizo_search_amd.foldclass import sharded
+rank, world, _dev = sharded.init_distributed()
+assert world == 2
+t = torch.ones(4) * (rank + 1)
+dist.all_reduce(t)                               # the exchange every rank takes part in
+assert float(t[0]) == 3.0
+if rank == 0:
+    time.sleep(5.0)                              # rank 0 alone reports
+    open(sys.argv[2], "w").write("written by rank 0\n")
+sharded.finalize_distributed()
+print("rank", rank, "finalized")
+""")
+    env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", MERIZO_DIST_TIMEOUT_S="2", OMP_NUM_THREADS="1")
+    out = tmp_path / "report.txt"
+    r = _torchrun(2, [str(script), REPO, str(out)], env, 24000 + os.getpid() % 10000)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert out.read_text() == "written by rank 0\n"
+    assert "rank 0 finalized" in r.stdout and "rank 1 finalized" in r.stdout
+
+
+def test_same_device_with_rccl_backend_is_refused(monkeypatch):
+    """MERIZO_SAME_DEVICE=1 (every rank on cuda:0) only works over gloo; with the default nccl backend RCCL would fail or
+    hang, so init_distributed says so up front."""
+    from merizo_search_amd.foldclass import sharded
+    monkeypatch.setenv("WORLD_SIZE", "2"); monkeypatch.setenv("RANK", "0"); monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("MERIZO_SAME_DEVICE", "1"); monkeypatch.delenv("MERIZO_DIST_BACKEND", raising=False)
+    with pytest.raises(RuntimeError, match="gloo"):
+        sharded.init_distributed()
+
+
 def test_balance_by_cost_is_a_partition_and_balanced():
     from merizo_search_amd.foldclass.sharded import balance_by_cost
     rng = np.random.default_rng(0)
@@ -199,3 +238,19 @@ print("rccl ok")
 ''')
     r = subprocess.run([sys.executable, str(script), REPO, str(23000 + os.getpid() % 10000)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launches_and_is_exact(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts its two ranks itself (a fresh child, never
+    an exec), here both on cuda:0 over gloo; the JSON line reports 2 GPUs, recall 1.0 and lists identical to a brute force."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MS_BENCH_SAME_DEVICE="1", MS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--rows", "600000", "--nq", "96", "--steps", "3",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 300000
+    assert line["recall_at_k"] == 1.0 and line["planted_recall"] == 1.0
+    assert line["topk_identical_to_torch_bruteforce"].startswith("96 of 96")

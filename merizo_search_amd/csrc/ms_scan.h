@@ -530,23 +530,36 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 }
 
 // ------------------------------------------------------------------ scan, loader-wave form
-// MFMA-bound batches (>= 3 query tiles, qwb == 4): the 4 compute waves of a workgroup scan the
-// SAME rows for 4 query tiles.  In ms_scan_body each of them fetches its own copy of every tile,
-// and the 16 LDS-DMA pieces per tile cost the issuing wave about 60 cycles each inside its MFMA
-// chain (4.1k -> 5.2k cycles per tile, in-kernel stamps).  Here a FIFTH wave does nothing but the
-// LDS-DMA: one copy of each tile into a ring of LDR_R slots shared by the workgroup, up to
-// LDR_D tiles in flight (counted s_waitcnt vmcnt), published through flag words in LDS; the
-// compute waves poll the flag of tile t+1 in the middle of chain t and report what they have
-// consumed.  No barrier: a wave delayed by insertions may trail the others by LDR_R - 1 tiles
-// before the loader has to wait for it.  (The kernel needs <= 256 registers per wave so that
-// the loader can share a SIMD with a compute wave: __launch_bounds__(320, 2).)
+// MFMA-bound batches (>= 3 query tiles, qwb == 4): the 4 compute waves of a workgroup scan the SAME rows for 4 query
+// tiles; a FIFTH wave does nothing but LDS-DMA: one copy of each tile into a ring of LDR_R slots shared by the
+// workgroup, up to LDR_D tiles in flight (counted s_waitcnt vmcnt), published through ONE counter in LDS (`landed`:
+// tiles are published in order); the compute waves look at it in the middle of chain t and report what they have
+// consumed (one ds_add per tile).  No barrier: a wave delayed by insertions may trail the others by LDR_R - 1 tiles
+// before the loader has to wait for it.  (The kernel needs <= 256 registers per wave so that the loader can share a
+// SIMD with a compute wave: __launch_bounds__(320, 2).)
+//
+// What a tile costs (tools/probes/mfma_price_probe.hip, profiles/r03_mfma_price_probe_v1.log): the dependent chain of
+// 64 v_mfma_f32_32x32x2_f32 runs at exactly 64 cycles per instruction (4096 per tile), but EVERY vector instruction the
+// wave issues between them costs the chain 8-15 cycles (the fp32 matrix instruction runs at the vector rate and the
+// two do not overlap inside one wave), and a second wave on the SIMD is starved while the chain runs
+// (tools/probes/pair_probe.hip), so the work cannot be handed to a partner either.  The stage is therefore written
+// to issue as few vector instructions as possible, and hipcc is not allowed to place them (it clusters ~60 of them
+// behind the last MFMAs of the chain): MFMAs and fillers are volatile asm statements in program order.
+//   * tile image in LDS is CHUNK-major, [16-byte chunk c = 0..31][row r = 0..31]: lane (r, h) reads its 16 fragments
+//     at base + 512 f (immediate offsets, f = 0..15, base = slot + 8192 h + 16 r): conflict free (the 16 lanes of a
+//     ds_read_b128 group have distinct r mod 16) with NO address arithmetic (the row-major XOR-swizzled image needs
+//     one v_xor per read).  The loader's LDS-DMA piece `it` gathers chunks 2 it, 2 it + 1 of all 32 rows (32 bytes
+//     per row; the four pieces that share a 128-byte line follow each other);
+//   * filter of tile t-1: 8 v_max3 fold the lane's 16 scores into one maximum, ONE compare per tile;
+//   * slot base of tile t+1: one v_add; loader flag: one ds_read_b32 + v_readfirstlane; consumed counter: ds_add
+//     under an EXEC mask set by scalar moves.  11 vector instructions per tile in inner-product mode.
 #ifndef MS_LDR_R
 #define MS_LDR_R 8
 #endif
 #ifndef MS_LDR_D
 #define MS_LDR_D 3
 #endif
-constexpr int LDR_R = MS_LDR_R;  // ring slots (tiles); 8 instead of 4 is worth 1.4 % per tile (stamps): fast waves may run further ahead
+constexpr int LDR_R = MS_LDR_R;  // ring slots (tiles)
 constexpr int LDR_D = MS_LDR_D;  // tiles the loader keeps in flight before publishing the oldest
 constexpr int LDR_AUX = 2 * LDR_R;   // aux (row scale / length) ring: a tile's aux data is read up to two stages after its slot was
                                      // released, while the loader may run LDR_R - 1 tiles ahead of the slowest wave
@@ -558,11 +571,9 @@ constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
 // before any later use of its own (LDS-DMA builtins, v_readlane / movrel with M0), so it stays.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds_addr), "v"(lane_off), "s"(sbase) : "memory", "m0");
-}
-__device__ __forceinline__ void ms_glds_v16(uint32_t lds_addr, const void *lane_ptr) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
+template <int IMM>
+__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset + immediate
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
 }
 __device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
@@ -582,19 +593,28 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int KL, bool AUX>
+// Pinned instructions of the compute waves' stage (volatile asm statements keep their program order).
+#define MS_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define MS_MFMA_Z(ACC, A, B) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "v"(B))   // C = 0 inline: a new chain
+#define MS_MAX3(M, A, B) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(M) : "v"(A), "v"(B))
+#define MS_FRAG_READ(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM) : "memory")
+
+// SAMPLE: the sample pass in this form -- no lists, every lane keeps the maximum of its half of the rows of the first
+// max_tiles FULL tiles of its stream; the two maxima of a lane pair (distinct rows) are the stream's entry for the
+// bound selection (ms_sample_bound_kernel looks at values only).
+template <int KL, bool AUX, bool SAMPLE>
 __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 compute, 4 loader
     const int r = lane & 31, h = lane >> 5;
-    // smem: LDR_R tile slots of 32 x 32 float4, then the aux ring, then the flag words
+    // smem: LDR_R tile slots of 16 KiB, then the aux ring, then the counters
     float *auxring = reinterpret_cast<float *>(smem + LDR_R * 16384);                 // LDR_AUX x 64 floats
-    // flag words, as explicit LDS (address space 3) pointers: a volatile access through a generic
+    // counters, as explicit LDS (address space 3) pointers: a volatile access through a generic
     // pointer compiles to flat_load + s_waitcnt vmcnt(0), hundreds of cycles in the middle of a chain
     typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
-    lds_flag_t *full = (lds_flag_t *)(smem + LDR_R * 16384 + LDR_AUX * 256);          // [LDR_R] tile+1 held by the slot
-    lds_flag_t *consumed = full + 8;                                                   // [4] tiles read by compute wave w
+    lds_flag_t *landed = (lds_flag_t *)(smem + LDR_R * 16384 + LDR_AUX * 256);        // [1] tiles published by the loader (in order)
+    lds_flag_t *consumed = landed + 8;                                                 // [4] tiles read by compute wave w
 
     const int bid = blockIdx.x;
     const int per_super = 8 * p.n_qgroups;
@@ -606,27 +626,26 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     const int64_t row_end = (row_begin + p.rows_per_stream < p.n) ? row_begin + p.rows_per_stream : p.n;
     const int nfull = (int)((row_end - row_begin) >> 5);
     const int rem = (int)((row_end - row_begin) & 31);
-    const int ntl = nfull + (rem > 0 ? 1 : 0);        // tiles the loader delivers (the last one may be partial)
+    // tiles the loader delivers: the whole stream (the last tile may be partial), or the first max_tiles FULL tiles (sample pass)
+    const int ntl = SAMPLE ? (nfull < p.max_tiles ? nfull : p.max_tiles) : nfull + (rem > 0 ? 1 : 0);
 
     if (tid < 16) {
         uint32_t v = 0;
         if (tid >= 8 && tid < 12) v = ((qg * 4 + (tid - 8)) < p.n_qtiles) ? 0u : 0xFFFFFFFFu;   // padding query tiles never block the loader
-        full[tid] = v;
+        landed[tid] = v;
     }
     __syncthreads();
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
 
     if (wave == 4) {
         // ---------------- loader ----------------
-        // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs
-        // back to back, so it is written to need as few instructions as possible: raised priority,
-        // and every LDS-DMA piece is one s_mov m0 + one global_load_lds with an SGPR base and a
-        // precomputed 32-bit lane offset (inline asm: hipcc's builtin form spends 2-5 VALU
-        // instructions per piece on 64-bit lane addresses).
+        // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs back to back, so it
+        // is written to need as few instructions as possible: raised priority, and every LDS-DMA piece is one s_mov m0 +
+        // one global_load_lds with an SGPR base, ONE lane-offset register and an immediate (inline asm).
         __builtin_amdgcn_s_setprio(3);
-        uint32_t voff[16];
-#pragma unroll
-        for (int it = 0; it < 16; ++it) voff[it] = (uint32_t)(it * 1024 + h * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
-        const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
+        // piece `it` -> LDS bytes [it * 1024, it * 1024 + 1024) of the slot = chunks 2 it (lanes 0-31) and 2 it + 1 (lanes 32-63)
+        // of rows r = lane & 31: source byte r * 512 + (2 it + h) * 16 = voff + 32 it
+        const uint32_t voff_full = (uint32_t)(r * 512 + h * 16);
         const uint32_t aux_lds = ring_lds + LDR_R * 16384;
 #ifdef MS_STAMP
         unsigned long long lst_poll = 0, lst_issue = 0, lst_vm = 0, lst_t0 = __builtin_amdgcn_s_memtime();
@@ -654,32 +673,29 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                 const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
                 ms_glds_v4(aux_lds + (uint32_t)(t % LDR_AUX) * 256u, base + row);
             }
-            if (row0 + 32 <= p.n) {
-                const uint64_t b = (uint64_t)(uintptr_t)p.db + (uint64_t)row0 * 512u;
-                const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);        // (the builtin returns int:
-                const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));  //  no sign extension)
-                const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
-#pragma unroll
-                for (int it = 0; it < 16; ++it) ms_glds_s16(slot_lds + it * 1024, voff[it], sb);
-            } else {       // last tile of the database: clamp rows past the end (their scores are discarded)
-#pragma unroll
-                for (int it = 0; it < 16; ++it) {
-                    int64_t row = row0 + 2 * it + h;
-                    if (row >= p.n) row = p.n - 1;
-                    ms_glds_v16(slot_lds + it * 1024,
-                                reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15)));
-                }
+            // last tile of the database: rows past the end re-read the last row (their scores are discarded)
+            uint32_t voff = voff_full;
+            if (row0 + 32 > p.n) {
+                const int last = (int)(p.n - 1 - row0);
+                voff = (uint32_t)((r < last ? r : last) * 512 + h * 16);
             }
+            const uint64_t b = (uint64_t)(uintptr_t)p.db + (uint64_t)row0 * 512u;
+            const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);        // (the builtin returns int:
+            const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));  //  no sign extension)
+            const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+#define MS_PIECE(IT) ms_glds_s16<32 * (IT)>(slot_lds + (IT) * 1024, voff, sb);
+            MS_PIECE(0) MS_PIECE(1) MS_PIECE(2) MS_PIECE(3) MS_PIECE(4) MS_PIECE(5) MS_PIECE(6) MS_PIECE(7)
+            MS_PIECE(8) MS_PIECE(9) MS_PIECE(10) MS_PIECE(11) MS_PIECE(12) MS_PIECE(13) MS_PIECE(14) MS_PIECE(15)
+#undef MS_PIECE
             LST(lst_issue)
             if (t >= LDR_D - 1) {                      // tile t - (D-1) has landed: publish it
                 ms_vmcnt_tiles<AUX, LDR_D - 1>();
-                const int tp = t - (LDR_D - 1);
-                if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+                if (lane == 0) landed[0] = (uint32_t)(t - (LDR_D - 1) + 1);
             }
             LST(lst_vm)
         }
 #ifdef MS_STAMP
-        if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+        if (!SAMPLE && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
             unsigned long long *o = p.stamps + ((size_t)bid * 8 + 4) * 8;
             o[0] = lst_poll; o[1] = lst_issue; o[2] = lst_vm; o[3] = (unsigned long long)ntl;
         }
@@ -687,13 +703,11 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // drain: publish the last D-1 tiles
         if (ntl >= 2) {
             ms_vmcnt_tiles<AUX, 1>();
-            const int tp = ntl - 2;
-            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+            if (lane == 0) landed[0] = (uint32_t)(ntl - 1);
         }
         if (ntl >= 1) {
             ms_vmcnt_tiles<AUX, 0>();
-            const int tp = ntl - 1;
-            if (lane == 0) full[tp % LDR_R] = (uint32_t)(tp + 1);
+            if (lane == 0) landed[0] = (uint32_t)ntl;
         }
         return;
     }
@@ -701,9 +715,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     // ---------------- compute waves ----------------
     const int qtile = qg * 4 + wave;
     if (qtile >= p.n_qtiles) return;
-    ScanState<KL> st;
+    ScanState<SAMPLE ? 1 : KL> st;
 #pragma unroll
-    for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
+    for (int j = 0; j < (SAMPLE ? 1 : KL); ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
     st.floor = -INFINITY;
 #ifdef MS_DEBUG_NO_INSERT
     st.tau = INFINITY;
@@ -712,7 +726,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
     const int qidx = qtile * 32 + r;
     const bool q_valid = qidx < p.nq;
-    if (p.lb_s != nullptr) {
+    if (!SAMPLE && p.lb_s != nullptr) {
         const float lb = p.lb_s[qidx];
         st.floor = (lb == -INFINITY) ? -INFINITY : nextafterf(lb, -INFINITY);
 #ifndef MS_DEBUG_NO_INSERT
@@ -737,7 +751,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 
     auto wait_tile = [&](int t) {          // until the loader has published tile t
         const uint32_t need = (uint32_t)(t + 1);
-        for (uint32_t spins = 0; __builtin_amdgcn_readfirstlane(full[t % LDR_R]) < need; ++spins) {
+        for (uint32_t spins = 0; __builtin_amdgcn_readfirstlane(landed[0]) < need; ++spins) {
             if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
             __builtin_amdgcn_s_sleep(1);
         }
@@ -766,65 +780,72 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             m[4 * g + j] = __ballot(pass);
         }
     };
-    // Inside the pipeline (full tiles, no upper bound) the filter is cheaper still: final scores of
-    // group g -> sc, and the lane's running maximum over the tile; ONE compare per tile decides
-    // whether any of the 32 x 32 scores can matter, the per-score ballots are taken only then.
-    auto scale_group = [&](f32x16 &acc, int t, int g, float &mx) {       // in place: acc <- final scores
-        f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (AUX) {
-            const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
-            inv4 = ax[0];
-            len4 = ax[8];
-        }
+    // cosine mode: final scores of group g of the previous tile, in place (the inner-product mode needs no such step)
+    auto scale_group = [&](f32x16 &acc, int t, int g) {
+        const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
+        const f32x4 inv4 = ax[0], len4 = ax[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float s = acc[4 * g + j];
-            if (AUX) {
-                float sv = s * inv4[j];
-                const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;
-                sv = sv * mk;
-                s = (t >= 0) ? sv : -INFINITY;
-                acc[4 * g + j] = s;
-            }
+            float sv = acc[4 * g + j] * inv4[j];
+            const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;
+            sv = sv * mk;
+            acc[4 * g + j] = (t >= 0) ? sv : -INFINITY;
         }
-        mx = fmaxf(mx, fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), fmaxf(acc[4 * g + 2], acc[4 * g + 3])));
     };
 
     f32x4 areg[16];
-    const uint32_t frag_a0 = (uint32_t)(r * 512 + 256 * h + 16 * (r & 15));    // fragment 0 of this lane inside a slot
+    const uint32_t lin0 = ring_lds + (uint32_t)(8192 * h + 16 * r);         // fragment f of this lane in slot s: lin0 + 16384 s + 512 f
+    const uint32_t landed_addr = ring_lds + LDR_R * 16384 + LDR_AUX * 256;
+    uint32_t cons_addr = landed_addr + 32 + 4 * wave, one = 1;
+    asm volatile("" : "+v"(cons_addr), "+v"(one));                          // keep both in vector registers across the loop
+    float smax = -INFINITY;                                                 // SAMPLE: this lane's best score so far
 #ifdef MS_STAMP
     unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
 #endif
-    auto stage = [&](int t, f32x16 &prev, f32x16 &out) {       // prev (raw scores of tile t-1) is scaled in place
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // tile t fully read into areg
-        if (lane == 0) consumed[wave] = (uint32_t)(t + 1);
-        // fragment f of this lane's row sits at float4 column (16 h + f) ^ (r & 15) of the slot:
-        // byte address = (slot + frag_a0) ^ (16 f) -- ONE address register and one v_xor per read
-        // instead of 16 precomputed lane offsets (the slot base has no bits below 2^14)
-        const uint32_t src_a0 = (uint32_t)(((t + 1) % LDR_R) * 16384) + frag_a0;
-        float sc[16];
-        uint64_t m[16];
-        float mx = -INFINITY;
-        uint32_t flag = 0;
-        f32x16 acc;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-#pragma unroll
-        for (int tt = 0; tt < 8; ++tt) {
-            const f32x4 a = areg[tt];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-            if (tt >= 2 && tt < 6) scale_group(prev, t - 1, tt - 2, mx);
-            if (tt == 4) {      // flag of tile t+1: read issued here, looked at three groups later (asm: hipcc would sink the read to its use)
-                const uint32_t fa = (uint32_t)(uintptr_t)(full + (t + 1) % LDR_R);     // LDS byte address
-                asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(fa) : "memory");
-                __builtin_amdgcn_sched_barrier(0);
-            }
+    // One stage = the chain of tile t (from areg) into `out`; in its gaps: the filter of tile t-1 (`prev`, raw scores;
+    // cosine mode scales them in place first), the look at the loader's counter and the refill of areg with tile t+1.
+    // After the chain: the rare insertion steps of tile t-1.
+    auto stage = [&](int t, f32x16 &prev, f32x16 &out) {
+        // tile t is complete in areg (the statement names areg so that no use of it is placed above the wait)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]), "+v"(areg[6]), "+v"(areg[7]),
+                       "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15])
+                     :: "memory");
+        // slot of tile t is free for the loader: lane 0 adds 1 to consumed[wave] (EXEC set by scalar moves: no vector instruction)
+        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(cons_addr), "v"(one) : "memory");
+        const uint32_t slot_off = (uint32_t)((t + 1) % LDR_R) * 16384u;
+        float mx;
+        uint32_t flag = 0, rbase;
+#define MS_GROUP(TT, FIRST)                                                                                   \
+        if (FIRST) { MS_MFMA_Z(out, areg[TT].x, qreg[4 * (TT) + 0]); } else { MS_MFMA(out, areg[TT].x, qreg[4 * (TT) + 0]); } \
+        MS_MFMA(out, areg[TT].y, qreg[4 * (TT) + 1]); MS_MFMA(out, areg[TT].z, qreg[4 * (TT) + 2]); MS_MFMA(out, areg[TT].w, qreg[4 * (TT) + 3]);
+#define MS_REFILL(TT) MS_FRAG_READ(areg[2 * ((TT) - 8)], rbase, 512 * (2 * ((TT) - 8))); MS_FRAG_READ(areg[2 * ((TT) - 8) + 1], rbase, 512 * (2 * ((TT) - 8) + 1));
+        MS_GROUP(0, true)
+        MS_GROUP(1, false)
+        if (AUX) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); __builtin_amdgcn_sched_barrier(0); }
+        MS_GROUP(2, false)
+        if (AUX) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); __builtin_amdgcn_sched_barrier(0); }
+        MS_GROUP(3, false)
+        // the lane's maximum over the 16 scores of tile t-1 (the running maximum of the whole sample in SAMPLE mode)
+        if (SAMPLE) {
+            MS_MAX3(smax, prev[0], prev[1]); MS_MAX3(smax, prev[2], prev[3]); MS_MAX3(smax, prev[4], prev[5]); MS_MAX3(smax, prev[6], prev[7]);
+        } else {
+            asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(prev[0]), "v"(prev[1]), "v"(prev[2]));
+            MS_MAX3(mx, prev[3], prev[4]); MS_MAX3(mx, prev[5], prev[6]); MS_MAX3(mx, prev[7], prev[8]);
         }
+        MS_GROUP(4, false)
+        if (SAMPLE) {
+            MS_MAX3(smax, prev[8], prev[9]); MS_MAX3(smax, prev[10], prev[11]); MS_MAX3(smax, prev[12], prev[13]); MS_MAX3(smax, prev[14], prev[15]);
+        } else {
+            MS_MAX3(mx, prev[9], prev[10]); MS_MAX3(mx, prev[11], prev[12]); MS_MAX3(mx, prev[13], prev[14]);
+            asm volatile("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(prev[15]));
+        }
+        // the loader's counter: read issued here, looked at two groups later
+        asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
+        MS_GROUP(5, false)
+        MS_GROUP(6, false)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_u32 %1, %2, %3" : "+v"(flag), "=v"(rbase) : "s"(slot_off), "v"(lin0) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) : : "memory");
         flag = __builtin_amdgcn_readfirstlane(flag);
 #ifdef MS_STAMP
         if (t + 1 < ntl && flag < (uint32_t)(t + 2)) {
@@ -836,29 +857,35 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #else
         if (t + 1 < ntl && flag < (uint32_t)(t + 2)) wait_tile(t + 1);   // normally long since published
 #endif
-#pragma unroll
-        for (int tt = 8; tt < 16; ++tt) {
-            const f32x4 a = areg[tt];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, qreg[4 * tt + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, qreg[4 * tt + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);
-            const int f0 = 2 * (tt - 8);        // fragments of groups already consumed <- tile t+1
-            areg[f0] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * f0)));
-            areg[f0 + 1] = *reinterpret_cast<const f32x4 *>(smem + (src_a0 ^ (uint32_t)(16 * (f0 + 1))));
-        }
-        out = acc;
-        if (__ballot(mx > st.tau) != 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        MS_GROUP(7, false)
+        // fragments of groups already consumed <- tile t+1 (past the last tile: a stale slot, never used)
+        MS_GROUP(8, false) MS_REFILL(8)
+        MS_GROUP(9, false) MS_REFILL(9)
+        MS_GROUP(10, false) MS_REFILL(10)
+        MS_GROUP(11, false) MS_REFILL(11)
+        MS_GROUP(12, false) MS_REFILL(12)
+        MS_GROUP(13, false) MS_REFILL(13)
+        MS_GROUP(14, false) MS_REFILL(14)
+        MS_GROUP(15, false) MS_REFILL(15)
+#undef MS_GROUP
+#undef MS_REFILL
+        __builtin_amdgcn_sched_barrier(0);
+        if (!SAMPLE) {
+            if (__ballot(mx > st.tau) != 0) {
 #ifdef MS_STAMP
-            const unsigned long long i0 = __builtin_amdgcn_s_memtime();
+                const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
+                float sc[16];
+                uint64_t m[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
-            ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+                for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
+                ms_tile_insert<SAMPLE ? 1 : KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
 #ifdef MS_STAMP
-            stamp_ins += __builtin_amdgcn_s_memtime() - i0;
-            stamp_nins += 1;
+                stamp_ins += __builtin_amdgcn_s_memtime() - i0;
+                stamp_nins += 1;
 #endif
+            }
         }
     };
 
@@ -871,7 +898,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
         wait_tile(0);
 #pragma unroll
-        for (int tt = 0; tt < 16; ++tt) areg[tt] = *reinterpret_cast<const f32x4 *>(smem + (frag_a0 ^ (uint32_t)(16 * tt)));
+        for (int f = 0; f < 16; ++f) areg[f] = *reinterpret_cast<const f32x4 *>(smem + (lin0 - ring_lds) + 512 * f);
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
@@ -883,19 +910,27 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             stage(t, acc0, acc1);
             acc0 = acc1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the last chain's result is read by compiler-scheduled code next: wait out the matrix pipe (the hazard
+        // recognizer does not see inside the asm statements)
+        asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)" : "+v"(acc0) :: "memory");
         if (lane == 0) consumed[wave] = 0xFFFFFFFFu;
-        float sc[16];
-        uint64_t m[16];
+        if (SAMPLE) {
+            if (AUX) { scale_group(acc0, ntl - 1, 0); scale_group(acc0, ntl - 1, 1); scale_group(acc0, ntl - 1, 2); scale_group(acc0, ntl - 1, 3); }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) filter_group(acc0, ntl - 1, g, true, sc, m);
-        uint64_t any = 0;
+            for (int i = 0; i < 16; ++i) smax = (acc0[i] > smax) ? acc0[i] : smax;       // (NaN scores never enter)
+        } else {
+            float sc[16];
+            uint64_t m[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) any |= m[i];
-        if (any != 0) ms_tile_insert<KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
+            for (int g = 0; g < 4; ++g) filter_group(acc0, ntl - 1, g, true, sc, m);
+            uint64_t any = 0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) any |= m[i];
+            if (any != 0) ms_tile_insert<SAMPLE ? 1 : KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
+        }
     }
 #ifdef MS_STAMP
-    if (p.max_tiles == 0 && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
+    if (!SAMPLE && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
         unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
         o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
@@ -904,8 +939,24 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         o[4] = stamp_ins; o[5] = stamp_nins;
     }
 #endif
+    if (SAMPLE) {
+        // the stream's entry: the two half-tile maxima of the lane pair (scores of distinct rows), larger first; rows are
+        // not recorded (the bound selection reads values only), a distinct placeholder keeps the slots "occupied"
+        const float other = ms_xor32_f(smax, h);
+        if (h == 0) {
+            const float hi = (other > smax) ? other : smax, lo = (other > smax) ? smax : other;
+            const size_t o = ((size_t)qidx * p.k + 0) * p.P + stream;
+            p.part_s[o] = hi;
+            p.part_i[o] = (hi > -INFINITY) ? (uint32_t)(2 * stream) : MS_IDX_NONE;
+            if (p.k > 1) {
+                p.part_s[o + p.P] = lo;
+                p.part_i[o + p.P] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
+            }
+        }
+        return;
+    }
 #pragma unroll
-    for (int j = 0; j < KL; ++j) {
+    for (int j = 0; j < (SAMPLE ? 1 : KL); ++j) {
         const int rank = h * KL + j;
         if (rank < p.k) {
             const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
@@ -952,9 +1003,9 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
     if constexpr ((KL <= 10 || (KL == 16 && !AUX)) && !UB) {    // loader-wave form: its compute waves must fit 256 registers
                                                                   // (16-entry lists only without the cosine-mode operands)
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX>),
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, false>),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
-            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, false>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
             MS_LAUNCH_CHECK("ms_scan_loader_kernel");
             return MS_OK;
         }
@@ -963,6 +1014,16 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes));
     hipLaunchKernelGGL((ms_scan_kernel<KL, AUX, UB>), dim3(pl.grid), dim3(256), pl.lds_bytes, st, sp);
     MS_LAUNCH_CHECK("ms_scan_kernel");
+    return MS_OK;
+}
+
+// Sample pass in the loader-wave form (qwb == 4), values only: one instantiation per mode, whatever the list length.
+template <bool AUX>
+int launch_sample_loader_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<5, AUX, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+    hipLaunchKernelGGL((ms_scan_loader_kernel<5, AUX, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+    MS_LAUNCH_CHECK("ms_scan_loader_kernel (sample)");
     return MS_OK;
 }
 
@@ -978,3 +1039,4 @@ int ms_launch_scan_kl10(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
 int ms_launch_scan_kl16(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
 int ms_launch_scan_kl32(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
 int ms_launch_scan_kl32ub(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);
+int ms_launch_sample_loader(const ScanPlan &pl, const ScanParams &sp, hipStream_t st);     // ms_scan_kl5.hip

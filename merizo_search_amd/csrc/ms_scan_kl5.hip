@@ -4,3 +4,8 @@
 int ms_launch_scan_kl5(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     return launch_scan_kl<5, false>(pl, sp, st);
 }
+
+int ms_launch_sample_loader(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    const bool aux = sp.inv_norm != nullptr || sp.lengths != nullptr;
+    return aux ? launch_sample_loader_variant<true>(pl, sp, st) : launch_sample_loader_variant<false>(pl, sp, st);
+}

@@ -569,7 +569,7 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     ScanParams s0 = *sp;
     s0.max_tiles = pl.prepass_tiles;
     s0.lb_s = nullptr;
-    int rc = launch_scan(pl, s0, st);
+    int rc = (pl.qwb == 4 && loader_wave_setting()) ? ms_launch_sample_loader(pl, s0, st) : launch_scan(pl, s0, st);
     if (rc) return rc;
     float *lb = reinterpret_cast<float *>(ws + pl.off_lb_s);
     // the sample kernel leaves at most 2 entries per (query, stream) and merges the 4 / qwb streams of a workgroup: only the

@@ -403,3 +403,42 @@ def test_cosine_mask_large_k_vs_reference_arithmetic(n, nq, k, torch_gpu):
                        lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
     s_ref, i_ref = orc.cosine_topk(raw, rq, k, lengths, qlen, 0.7)
     assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+
+
+@pytest.mark.parametrize("n", [100_000, 400_000])
+@pytest.mark.parametrize("nq", [8, 96])
+def test_cosine_mask_zero_ties_under_the_sample_bound(n, nq, torch_gpu):
+    """The sample pass is active here (nq >= 8, >= 12 tiles per stream).  Queries so short that EVERY row is masked have
+    all scores +-0.0 (reference dbsearch.py:76-79: the mask multiplies, it does not exclude), so their sample bound is
+    lb = +-0.0 and the full pass runs on floor = nextbelow(0) = -1.4e-45, a denormal threshold; queries with fewer than k
+    unmasked rows end their lists in zeros.  Indices and sign bits as the oracle's: all-masked lists are rows 0..k-1 in
+    ascending order (easy-search of short domains against CATH)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    k, mincov = 10, 0.7
+    db, lengths = syn.raw_database(n, seed=61 + nq)
+    lengths = lengths.copy()
+    short = np.random.default_rng(5).choice(n, 7, replace=False)         # a handful of very short targets
+    lengths[short] = np.array([20, 20, 21, 22, 24, 25, 26], np.float32)[: len(short)]
+    q, qlen = syn.raw_queries(nq, seed=62)
+    qlen = qlen.copy()
+    qlen[0::4] = 3.0                  # every row masked: 3 >= len * 0.7 never holds (len >= 20)
+    qlen[1::4] = 15.0                 # unmasked rows: only targets with len <= 21.4 -> 3 rows (< k)
+    qlen[2::4] = 17.0                 # unmasked rows: len <= 24.3 -> 5 rows (< k)
+    d_db = _dev(torch, db)
+    inv = ops.row_inv_norms(d_db)
+    s, i = ops.ip_topk(d_db, _dev(torch, q), k, mode=ops.MODE_COSINE_RAW, inv_norm=inv, lengths=_dev(torch, lengths),
+                       qlen=_dev(torch, qlen), mincov=mincov)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    s_ref, i_ref = orc.cosine_topk(db, q, k, lengths, qlen, mincov)
+    assert_topk_equivalent(s, i, s_ref, i_ref, tol=COS_TOL)
+    allm = np.arange(0, nq, 4)
+    assert (s[allm] == 0.0).all() and np.array_equal(i[allm], np.tile(np.arange(k), (len(allm), 1)))
+    assert np.array_equal(np.signbit(s[allm]), np.signbit(s_ref[allm]))
+    for j in range(1, nq, 4):         # 3 unmasked rows: positive cosines first, then zeros of the masked rows by ascending row
+        pos = int((s_ref[j] > 0).sum())
+        assert np.array_equal(i[j, :pos], i_ref[j, :pos])
+        zero = s_ref[j] == 0.0
+        assert np.array_equal(i[j, zero], i_ref[j, zero]) and np.array_equal(np.signbit(s[j, zero]), np.signbit(s_ref[j, zero]))

@@ -571,9 +571,11 @@ constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
 // before any later use of its own (LDS-DMA builtins, v_readlane / movrel with M0), so it stays.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
+// SGPR base + 32-bit lane offset + immediate.  The immediate is added to the global address AND to the LDS address
+// (tools/probes/glds_offset_probe.hip), so M0 carries the destination minus the immediate.
 template <int IMM>
-__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {   // SGPR base + 32-bit lane offset + immediate
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
+__device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
 }
 __device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
@@ -593,6 +595,11 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+#ifdef MS_ABL_NOFLAG
+#define MS_ABL_NOFLAG_ 1
+#else
+#define MS_ABL_NOFLAG_ 0
+#endif
 // Pinned instructions of the compute waves' stage (volatile asm statements keep their program order).
 #define MS_MFMA(ACC, A, B) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
 #define MS_MFMA_Z(ACC, A, B) asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=v"(ACC) : "v"(A), "v"(B))   // C = 0 inline: a new chain
@@ -749,12 +756,14 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;      // no lengths: +inf >= x * 0
     const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
 
-    auto wait_tile = [&](int t) {          // until the loader has published tile t
+    auto wait_tile = [&](int t) -> uint32_t {          // until the loader has published tile t; returns the counter
         const uint32_t need = (uint32_t)(t + 1);
-        for (uint32_t spins = 0; __builtin_amdgcn_readfirstlane(landed[0]) < need; ++spins) {
+        uint32_t seen;
+        for (uint32_t spins = 0; (seen = (uint32_t)__builtin_amdgcn_readfirstlane(landed[0])) < need; ++spins) {
             if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
             __builtin_amdgcn_s_sleep(1);
         }
+        return seen;
     };
     auto filter_group = [&](const f32x16 &acc, int t, int g, bool check_rows, float (&sc)[16], uint64_t (&m)[16]) {
         const int64_t sub_row0 = row_begin + (int64_t)t * 32;
@@ -799,6 +808,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     uint32_t cons_addr = landed_addr + 32 + 4 * wave, one = 1;
     asm volatile("" : "+v"(cons_addr), "+v"(one));                          // keep both in vector registers across the loop
     float smax = -INFINITY;                                                 // SAMPLE: this lane's best score so far
+    uint32_t landed_seen = 0;                                               // the loader's counter as this wave last saw it (scalar)
 #ifdef MS_STAMP
     unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
 #endif
@@ -812,7 +822,11 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                        "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15])
                      :: "memory");
         // slot of tile t is free for the loader: lane 0 adds 1 to consumed[wave] (EXEC set by scalar moves: no vector instruction)
+#ifdef MS_ABL_NOEXEC
+        asm volatile("ds_add_u32 %0, %1" ::"v"(cons_addr), "v"(one) : "memory");
+#else
         asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(cons_addr), "v"(one) : "memory");
+#endif
         const uint32_t slot_off = (uint32_t)((t + 1) % LDR_R) * 16384u;
         float mx;
         uint32_t flag = 0, rbase;
@@ -827,36 +841,53 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         if (AUX) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); __builtin_amdgcn_sched_barrier(0); }
         MS_GROUP(3, false)
         // the lane's maximum over the 16 scores of tile t-1 (the running maximum of the whole sample in SAMPLE mode)
+#ifdef MS_ABL_NOMAX
+        mx = prev[0];
+#define MS_MAX3_(M, A, B)
+#else
+#define MS_MAX3_(M, A, B) MS_MAX3(M, A, B)
+#endif
         if (SAMPLE) {
             MS_MAX3(smax, prev[0], prev[1]); MS_MAX3(smax, prev[2], prev[3]); MS_MAX3(smax, prev[4], prev[5]); MS_MAX3(smax, prev[6], prev[7]);
         } else {
+#ifndef MS_ABL_NOMAX
             asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(prev[0]), "v"(prev[1]), "v"(prev[2]));
-            MS_MAX3(mx, prev[3], prev[4]); MS_MAX3(mx, prev[5], prev[6]); MS_MAX3(mx, prev[7], prev[8]);
+#endif
+            MS_MAX3_(mx, prev[3], prev[4]); MS_MAX3_(mx, prev[5], prev[6]); MS_MAX3_(mx, prev[7], prev[8]);
         }
         MS_GROUP(4, false)
         if (SAMPLE) {
             MS_MAX3(smax, prev[8], prev[9]); MS_MAX3(smax, prev[10], prev[11]); MS_MAX3(smax, prev[12], prev[13]); MS_MAX3(smax, prev[14], prev[15]);
         } else {
-            MS_MAX3(mx, prev[9], prev[10]); MS_MAX3(mx, prev[11], prev[12]); MS_MAX3(mx, prev[13], prev[14]);
+            MS_MAX3_(mx, prev[9], prev[10]); MS_MAX3_(mx, prev[11], prev[12]); MS_MAX3_(mx, prev[13], prev[14]);
+#ifndef MS_ABL_NOMAX
             asm volatile("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(prev[15]));
+#endif
         }
-        // the loader's counter: read issued here, looked at two groups later
-        asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
+        // The loader's counter.  A look at it costs the chain a vector instruction plus a scalar dependency (v_readfirstlane ->
+        // s_cmp -> branch: ~120 cycles in the stamps), so the wave keeps the last value it saw in a scalar register and looks
+        // again only when that no longer covers tile t+1: the wave that sets the workgroup's pace (the one that shares its SIMD
+        // with the loader) trails the loader by several tiles and looks once every few tiles.
+        const bool look = !MS_ABL_NOFLAG_ && (landed_seen < (uint32_t)(t + 2)) && (t + 1 < ntl);
+        if (look) asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
         MS_GROUP(5, false)
         MS_GROUP(6, false)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\tv_add_u32 %1, %2, %3" : "+v"(flag), "=v"(rbase) : "s"(slot_off), "v"(lin0) : "memory");
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(rbase) : "s"(slot_off), "v"(lin0));
         __builtin_amdgcn_sched_barrier(0);
-        flag = __builtin_amdgcn_readfirstlane(flag);
+        if (__builtin_expect(look, 0)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) :: "memory");
+            landed_seen = __builtin_amdgcn_readfirstlane(flag);
+            if (landed_seen < (uint32_t)(t + 2)) {          // normally long since published
 #ifdef MS_STAMP
-        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) {
-            const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-            wait_tile(t + 1);
-            stamp_wait += __builtin_amdgcn_s_memtime() - w0;
-            stamp_nwait += 1;
-        }
-#else
-        if (t + 1 < ntl && flag < (uint32_t)(t + 2)) wait_tile(t + 1);   // normally long since published
+                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
 #endif
+                landed_seen = wait_tile(t + 1);
+#ifdef MS_STAMP
+                stamp_wait += __builtin_amdgcn_s_memtime() - w0;
+                stamp_nwait += 1;
+#endif
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
         MS_GROUP(7, false)
         // fragments of groups already consumed <- tile t+1 (past the last tile: a stale slot, never used)
@@ -870,9 +901,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         MS_GROUP(15, false) MS_REFILL(15)
 #undef MS_GROUP
 #undef MS_REFILL
+#undef MS_MAX3_
         __builtin_amdgcn_sched_barrier(0);
         if (!SAMPLE) {
-            if (__ballot(mx > st.tau) != 0) {
+            if (__builtin_expect(__ballot(mx > st.tau) != 0, 0)) {
 #ifdef MS_STAMP
                 const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -891,18 +923,22 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 
 #ifdef MS_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long stamp_cm = stamp_c0, stamp_rm = stamp_r0;
 #endif
     if (ntl > 0) {
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
-        wait_tile(0);
+        landed_seen = wait_tile(0);
 #pragma unroll
         for (int f = 0; f < 16; ++f) areg[f] = *reinterpret_cast<const f32x4 *>(smem + (lin0 - ring_lds) + 512 * f);
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
         for (; t + 1 < ntl; t += 2) {
+#ifdef MS_STAMP
+            if (t == (ntl / 4) * 2) { stamp_cm = __builtin_amdgcn_s_memtime(); stamp_rm = __builtin_amdgcn_s_memrealtime(); }
+#endif
             stage(t, acc0, acc1);
             stage(t + 1, acc1, acc0);
         }
@@ -934,6 +970,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;
         o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
         o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
+        o[6] = stamp_cm - stamp_c0; o[7] = stamp_rm - stamp_r0;      // first half of the stream (cycles, 100 MHz ticks)
         o[2] = (unsigned long long)ntl;
         o[3] = (stamp_nwait << 40) | stamp_wait;
         o[4] = stamp_ins; o[5] = stamp_nins;

@@ -36,6 +36,11 @@ for n, nq, k in cases:
     print(f"   insert path: taken in {100*ni.sum()/st[:,2].astype(np.float64).sum():.1f}% of tiles, {ci.sum()/max(ni.sum(),1):.0f} cycles per visit")
     cyc, rt, nt = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64), st[:, 2].astype(np.float64)
     ghz = cyc / rt * 0.1
+    c1, r1 = st[:, 6].astype(np.float64), st[:, 7].astype(np.float64)
+    ok = (r1 > 0) & (rt > r1)
+    if ok.any():
+        print(f"   clock first half {np.median(c1[ok] / r1[ok]) * 0.1:.3f} GHz, second half {np.median((cyc[ok] - c1[ok]) / (rt[ok] - r1[ok])) * 0.1:.3f} GHz; "
+              f"first half takes {np.median(r1[ok]) / 100:.1f} us, second {np.median(rt[ok] - r1[ok]) / 100:.1f} us")
     nwait = (st[:, 3] >> np.uint64(40)).astype(np.float64); cwait = (st[:, 3] & np.uint64((1 << 40) - 1)).astype(np.float64)
     print(f"   flag misses/wave median {np.median(nwait):.0f} max {nwait.max():.0f}; wait cycles/tile median {np.median(cwait/nt):.0f} max {np.max(cwait/nt):.0f}")
     print(f"n={n} nq={nq}: scan kernel {e0.elapsed_time(e1)*1e3:.1f} us | waves {len(st)} tiles/wave {nt.mean():.0f} | "

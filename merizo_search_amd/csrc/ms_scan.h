@@ -22,6 +22,8 @@ struct ScanParams {
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;
     const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
+    uint32_t *hist;         // [nq_pad][16] candidates counted per score bucket during the full pass (loader-wave form), or NULL
+    const float *hstep;     // [nq_pad] bucket width of a query (bucket j starts at lb + j * step); 0 = no histogram for it
     int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
@@ -69,13 +71,43 @@ struct ScanState {
     float floor;   // largest float below the sample pass's lower bound (-inf without one)
 };
 
+// Shared lower bound of the full pass (loader-wave form).  A stream's own list hardly ever tightens the sample's bound
+// (a query has ~2 rows above it per stream), so every wave would keep visiting the insertion path for rows that cannot
+// reach the top k of the WHOLE shard: ~270 per query at C2, where ~40 would do with a bound that follows the scan.
+// Exchange, cheap on both sides: every candidate a wave accepts is counted in one of 16 score buckets of its query
+// (one no-return agent-scope atomic add; bucket j = scores >= lb + j * step, the last one open-ended), and every 16
+// tiles a wave reads its queries' 16 counters (sc1 loads: counters only grow, a stale value is just a weaker bound)
+// and raises its threshold to the highest bucket edge that already has k rows at or above it.  Rows are visited once
+// per query, so the counts are of distinct rows and the edge is a valid inclusive lower bound on the k-th best.
+struct ScanHist {
+    uint32_t *counters;    // this lane's query: 16 counters (NULL: off)
+    float base, step, inv_step;
+};
+__device__ __forceinline__ float ms_next_below(float x) {        // largest float below a finite x
+    uint32_t u = __float_as_uint(x);
+    u = (x > 0.0f) ? u - 1u : ((x < 0.0f) ? u + 1u : 0x80000001u);
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ float ms_hist_edge(const ScanHist &hg, int j) { return fmaf((float)j, hg.step, hg.base); }
+__device__ __forceinline__ void ms_hist_count(const ScanHist &hg, float v) {        // v >= base (it passed the filter)
+    int j = (int)((v - hg.base) * hg.inv_step);
+    j = j > 15 ? 15 : (j < 0 ? 0 : j);
+    if (v < ms_hist_edge(hg, j)) j -= 1;       // the bucket is decided by the same expression the readers evaluate
+    j = j < 0 ? 0 : j;
+    __hip_atomic_fetch_add(hg.counters + j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]
 // one insertion step: the candidate of row `crow` (score v in lanes of half hh whose bit is set
 // in mm) goes into the lists of all 32 queries at once
-template <int KL>
-__device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32_t mm, int hh, uint32_t crow, int r, int h) {
+template <int KL, bool HIST = false>
+__device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32_t mm, int hh, uint32_t crow, int r, int h,
+                                              const ScanHist *hg = nullptr) {
     // candidate of this lane pair (or -inf); re-checked against the current tau
     const bool mine = (h == hh) && ((mm >> r) & 1u) && (v > st.tau);
+    if (HIST) {
+        if (mine && hg->counters != nullptr) ms_hist_count(*hg, v);
+    }
     const float c = mine ? v : -INFINITY;
     const float pc = ms_xor32_f(c, h);
     const float cand = (h == hh) ? c : pc;
@@ -113,9 +145,9 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
 #ifndef MS_STATIC_INSERT_MAX_KL
 #define MS_STATIC_INSERT_MAX_KL 32
 #endif
-template <int KL>
+template <int KL, bool HIST = false>
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
-                                               int64_t sub_row0, int r, int h) {
+                                               int64_t sub_row0, int r, int h, const ScanHist *hg = nullptr) {
     if (KL <= MS_STATIC_INSERT_MAX_KL) {
         // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
@@ -128,7 +160,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
                     const uint64_t mj = m[4 * g + j];
                     const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
                     if (mm == 0) continue;
-                    ms_row_insert<KL>(st, sc[4 * g + j], mm, hh, (uint32_t)(sub_row0 + 8 * g + 4 * hh + j), r, h);
+                    ms_row_insert<KL, HIST>(st, sc[4 * g + j], mm, hh, (uint32_t)(sub_row0 + 8 * g + 4 * hh + j), r, h, hg);
                 }
             }
         }
@@ -143,7 +175,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
             for (int i = 1; i < 16; ++i) { mj = (reg == i) ? m[i] : mj; v = (reg == i) ? sc[i] : v; }
             const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
             if (mm == 0) continue;
-            ms_row_insert<KL>(st, v, mm, hh, (uint32_t)(sub_row0 + row), r, h);
+            ms_row_insert<KL, HIST>(st, v, mm, hh, (uint32_t)(sub_row0 + row), r, h, hg);
         }
     }
 }
@@ -741,6 +773,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
     }
     if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
+    ScanHist hg;
+    hg.counters = nullptr; hg.base = 0.0f; hg.step = 0.0f; hg.inv_step = 0.0f;
+    const bool hist_on = !SAMPLE && p.hist != nullptr && p.lb_s != nullptr;      // (uniform)
+    if (hist_on && q_valid) {
+        const float stp = p.hstep[qidx], lb = p.lb_s[qidx];
+        if (stp > 0.0f && lb > -INFINITY) { hg.counters = p.hist + (size_t)qidx * 16; hg.base = lb; hg.step = stp; hg.inv_step = 1.0f / stp; }
+    }
     float qreg[64];
     {
         const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
@@ -829,7 +868,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
         const uint32_t slot_off = (uint32_t)((t + 1) % LDR_R) * 16384u;
         float mx;
-        uint32_t flag = 0, rbase;
+        uint32_t flag, rbase;
 #define MS_GROUP(TT, FIRST)                                                                                   \
         if (FIRST) { MS_MFMA_Z(out, areg[TT].x, qreg[4 * (TT) + 0]); } else { MS_MFMA(out, areg[TT].x, qreg[4 * (TT) + 0]); } \
         MS_MFMA(out, areg[TT].y, qreg[4 * (TT) + 1]); MS_MFMA(out, areg[TT].z, qreg[4 * (TT) + 2]); MS_MFMA(out, areg[TT].w, qreg[4 * (TT) + 3]);
@@ -868,8 +907,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // s_cmp -> branch: ~120 cycles in the stamps), so the wave keeps the last value it saw in a scalar register and looks
         // again only when that no longer covers tile t+1: the wave that sets the workgroup's pace (the one that shares its SIMD
         // with the loader) trails the loader by several tiles and looks once every few tiles.
+        // (the LDS read itself is issued every tile: it costs no vector instruction, and a branch around it would)
+        asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
         const bool look = !MS_ABL_NOFLAG_ && (landed_seen < (uint32_t)(t + 2)) && (t + 1 < ntl);
-        if (look) asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
         MS_GROUP(5, false)
         MS_GROUP(6, false)
         asm volatile("v_add_u32 %0, %1, %2" : "=v"(rbase) : "s"(slot_off), "v"(lin0));
@@ -912,7 +952,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                 uint64_t m[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
-                ms_tile_insert<SAMPLE ? 1 : KL>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h);
+                ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
 #ifdef MS_STAMP
                 stamp_ins += __builtin_amdgcn_s_memtime() - i0;
                 stamp_nins += 1;
@@ -935,12 +975,39 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 hc0, hc1, hc2, hc3;
         for (; t + 1 < ntl; t += 2) {
 #ifdef MS_STAMP
             if (t == (ntl / 4) * 2) { stamp_cm = __builtin_amdgcn_s_memtime(); stamp_rm = __builtin_amdgcn_s_memrealtime(); }
 #endif
+            // shared bound (ScanHist): every 16th tile this query's 16 bucket counters are fetched (sc1: past this CU's L1)
+            // while two tiles are multiplied, then the threshold is raised.  The two tests are evaluated separately on purpose
+            // (kept apart by the empty asm): carried from one to the other, hipcc keeps the flag in a vector register.
+            if (hist_on && (t & 15) == 8) {
+                const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
+                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                             "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
+                             : "=&v"(hc0), "=&v"(hc1), "=&v"(hc2), "=&v"(hc3) : "v"(hp) : "memory");
+            }
             stage(t, acc0, acc1);
             stage(t + 1, acc1, acc0);
+            int t2 = t;
+            asm volatile("" : "+s"(t2));
+            if (hist_on && (t2 & 15) == 8) {
+                // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
+                const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
+                uint32_t cum = 0;
+                int n_lt = 0;
+#pragma unroll
+                for (int j = 15; j >= 0; --j) { cum += c[j]; n_lt += (cum < (uint32_t)p.k) ? 1 : 0; }
+                const int J = 15 - n_lt;
+                if (hg.counters != nullptr && J >= 1) {
+                    st.floor = fmaxf(st.floor, ms_next_below(ms_hist_edge(hg, J)));
+                    st.tau = fmaxf(st.tau, st.floor);
+                }
+            }
         }
         if (t < ntl) {
             stage(t, acc0, acc1);
@@ -962,7 +1029,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             uint64_t any = 0;
 #pragma unroll
             for (int i = 0; i < 16; ++i) any |= m[i];
-            if (any != 0) ms_tile_insert<SAMPLE ? 1 : KL>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h);
+            if (any != 0) ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(ntl - 1) * 32, r, h, &hg);
         }
     }
 #ifdef MS_STAMP
@@ -1019,7 +1086,7 @@ struct ScanPlan {
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
     size_t lds_bytes;
     // workspace carve (byte offsets)
-    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, total;
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, total;
 };
 
 inline int loader_wave_setting() {

@@ -273,7 +273,8 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 // Values only (no rows, no sorted output): one wave per query, the values in registers, k rounds of "largest value
 // below the previous one + how many lanes hold it".  -inf when there are fewer than k sampled rows.
 template <int VPL>      // values per lane: ranks * P <= 64 * VPL
-__global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb) {
+__global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb, uint32_t *hist,
+                                                            float *hstep) {
     const int q = blockIdx.x, lane = threadIdx.x;
     const float *ps = part_s + (size_t)q * k * P;              // rank-major [k][P]: the first ranks * P floats
     const int count = ranks * P;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
         const int idx = lane + 64 * i;
         v[i] = idx < count ? ps[idx] : -INFINITY;
     }
-    float cur = INFINITY, kth = -INFINITY;
+    float cur = INFINITY, kth = -INFINITY, top = -INFINITY;
     int remaining = k;
     for (int round = 0; round < k; ++round) {
         float m = -INFINITY;
@@ -295,6 +296,7 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 #undef MS_DPP_FMAX
         m = fmaxf(fmaxf(ms_readlane_f(m, 0), ms_readlane_f(m, 16)), fmaxf(ms_readlane_f(m, 32), ms_readlane_f(m, 48)));
         if (!(m > -INFINITY)) break;                              // fewer than k values: no bound
+        if (round == 0) top = m;
         int c = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) c += __popcll(__ballot(v[i] == m));
@@ -303,6 +305,17 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
         cur = m;
     }
     if (lane == 0) lb[q] = kth;
+    // Score buckets of the full pass's shared bound (ScanHist): the k-th best of the whole shard sits near the sample's BEST
+    // score (the sample is a few percent of the rows), so 16 buckets of (best - k-th) / 12 from the k-th up cover the range
+    // the bound moves through; the last bucket is open-ended.  No usable spread: step 0 = no histogram for this query.
+    if (hist != nullptr) {
+        if (lane < 16) hist[(size_t)q * 16 + lane] = 0u;
+        if (lane == 0) {
+            float step = (kth > -INFINITY && top > kth) ? (top - kth) * (1.0f / 12.0f) : 0.0f;
+            if (!(step > 0.0f) || !(step < INFINITY) || !(1.0f / step < INFINITY)) step = 0.0f;
+            hstep[q] = step;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ public k-way merge -
@@ -400,6 +413,12 @@ int sample_min_queries_setting() {
     return v;
 }
 
+int hist_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_SHARED_BOUND"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = no shared bound
+    return v;
+}
+
 int prepass_tiles_setting() {
     static int v = -2;
     if (v == -2) {
@@ -466,6 +485,8 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.off_lb_i = off;    off += ms_align_up((size_t)pl.nq_pad * sizeof(uint32_t), 256);
     pl.off_scr_s = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(float), 256);
     pl.off_scr_i = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(int64_t), 256);
+    pl.off_hist = off;    off += ms_align_up((size_t)pl.nq_pad * 16 * sizeof(uint32_t), 256);
+    pl.off_hstep = off;   off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
     pl.total = off;
     return pl;
 }
@@ -552,6 +573,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
+    sp->hist = nullptr; sp->hstep = nullptr;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -577,13 +599,17 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     const int ranks = (2 * (4 / pl.qwb) < s0.k) ? 2 * (4 / pl.qwb) : s0.k;
     const int vpl = (ranks * pl.P + 63) / 64;
     if (vpl <= 32) {
-#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb)
+        const bool hist_on = pl.qwb == 4 && loader_wave_setting() && hist_setting();
+        uint32_t *hist = hist_on ? reinterpret_cast<uint32_t *>(ws + pl.off_hist) : nullptr;
+        float *hstep = reinterpret_cast<float *>(ws + pl.off_hstep);
+#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb, hist, hstep)
         if (vpl <= 4) { MS_BOUND(4); }
         else if (vpl <= 8) { MS_BOUND(8); }
         else if (vpl <= 16) { MS_BOUND(16); }
         else { MS_BOUND(32); }
 #undef MS_BOUND
         MS_LAUNCH_CHECK("ms_sample_bound_kernel");
+        if (hist_on) { sp->hist = hist; sp->hstep = hstep; }
     } else {
         float *scratch_s = reinterpret_cast<float *>(ws + pl.off_scr_s);
         int64_t *scratch_i = reinterpret_cast<int64_t *>(ws + pl.off_scr_i);
@@ -697,7 +723,15 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
     ScanParams sp;
     // same parameters as ms_ip_topk_prepare left in the workspace (queries, inverse norms, lower bound)
     fill_scan_params(pl, db, n, q, nq, inv_norm, lengths, qlen, mincov, ws, mode, &sp);
-    if (pl.prepass_tiles > 0) sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
+    if (pl.prepass_tiles > 0) {
+        sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
+        if (pl.qwb == 4 && loader_wave_setting() && hist_setting()) {      // as run_prepass left them
+            sp.hist = reinterpret_cast<uint32_t *>(ws + pl.off_hist);
+            sp.hstep = reinterpret_cast<const float *>(ws + pl.off_hstep);
+            // the counters must start at zero for EVERY scan (a second scan after one prepare would otherwise count rows twice)
+            MS_HIP_CHECK(hipMemsetAsync(sp.hist, 0, (size_t)pl.nq_pad * 16 * sizeof(uint32_t), (hipStream_t)stream));
+        }
+    }
     return launch_scan(pl, sp, (hipStream_t)stream);
 }
 

@@ -6,6 +6,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <type_traits>
 
 // ------------------------------------------------------------------ scan kernel --------
 struct ScanParams {
@@ -694,7 +695,11 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
         for (int t = 0; t < ntl; ++t) {
             if (t >= LDR_R) {                          // slot t % R is free once everybody has read tile t - R
+#ifdef MS_ABL_EXEC1
                 const uint32_t need = (uint32_t)(t - LDR_R + 1);
+#else
+                const uint32_t need = (uint32_t)(t - LDR_R + 1) * 64u;      // (every lane of a compute wave adds: units of 64)
+#endif
                 for (uint32_t spins = 0;; ++spins) {
                     const uint32_t c0 = consumed[0], c1 = consumed[1], c2 = consumed[2], c3 = consumed[3];
                     const uint32_t m01 = c0 < c1 ? c0 : c1, m23 = c2 < c3 ? c2 : c3;
@@ -722,7 +727,11 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);        // (the builtin returns int:
             const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));  //  no sign extension)
             const uint64_t sb = ((uint64_t)b_hi << 32) | (uint64_t)b_lo;
+#ifdef MS_ABL_NODMA
+#define MS_PIECE(IT)
+#else
 #define MS_PIECE(IT) ms_glds_s16<32 * (IT)>(slot_lds + (IT) * 1024, voff, sb);
+#endif
             MS_PIECE(0) MS_PIECE(1) MS_PIECE(2) MS_PIECE(3) MS_PIECE(4) MS_PIECE(5) MS_PIECE(6) MS_PIECE(7)
             MS_PIECE(8) MS_PIECE(9) MS_PIECE(10) MS_PIECE(11) MS_PIECE(12) MS_PIECE(13) MS_PIECE(14) MS_PIECE(15)
 #undef MS_PIECE
@@ -795,8 +804,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;      // no lengths: +inf >= x * 0
     const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
 
-    auto wait_tile = [&](int t) -> uint32_t {          // until the loader has published tile t; returns the counter
-        const uint32_t need = (uint32_t)(t + 1);
+    auto wait_landed = [&](uint32_t need) -> uint32_t {          // until the loader has published `need` tiles; returns the counter
         uint32_t seen;
         for (uint32_t spins = 0; (seen = (uint32_t)__builtin_amdgcn_readfirstlane(landed[0])) < need; ++spins) {
             if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
@@ -843,9 +851,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 
     f32x4 areg[16];
     const uint32_t lin0 = ring_lds + (uint32_t)(8192 * h + 16 * r);         // fragment f of this lane in slot s: lin0 + 16384 s + 512 f
-    const uint32_t landed_addr = ring_lds + LDR_R * 16384 + LDR_AUX * 256;
-    uint32_t cons_addr = landed_addr + 32 + 4 * wave, one = 1;
-    asm volatile("" : "+v"(cons_addr), "+v"(one));                          // keep both in vector registers across the loop
+    uint32_t landed_addr = ring_lds + LDR_R * 16384 + LDR_AUX * 256;
+    uint32_t cons_addr = landed_addr + 32 + 4 * wave, two = 2, flag = 0;
+    asm volatile("" : "+v"(cons_addr), "+v"(two), "+v"(flag), "+v"(landed_addr));     // kept in vector registers across the loop
     float smax = -INFINITY;                                                 // SAMPLE: this lane's best score so far
     uint32_t landed_seen = 0;                                               // the loader's counter as this wave last saw it (scalar)
 #ifdef MS_STAMP
@@ -854,23 +862,51 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     // One stage = the chain of tile t (from areg) into `out`; in its gaps: the filter of tile t-1 (`prev`, raw scores;
     // cosine mode scales them in place first), the look at the loader's counter and the refill of areg with tile t+1.
     // After the chain: the rare insertion steps of tile t-1.
-    auto stage = [&](int t, f32x16 &prev, f32x16 &out) {
+    // Synchronisation with the loader is per PAIR of tiles (the loop runs two stages per iteration): before the first
+    // stage of a pair the wave makes sure that both tiles the pair will refill from have landed -- from the counter value
+    // it cached, or from the copy of the counter the previous stage left in `flag` (one v_readfirstlane, only when the
+    // cached value does not cover the pair), or by waiting; the second stage reports both tiles as consumed (every lane
+    // adds to the counter: it counts in units of 64, and no EXEC juggling sits in front of the chain) and re-reads the
+    // loader's counter into `flag` for the next pair.  The chain itself contains no branch and no scalar dependency.
+    auto ensure_landed = [&](int t) {            // before the first stage of a pair: tiles t+1 and t+2 (as far as they exist)
+        const uint32_t need = (uint32_t)((t + 3 < ntl) ? t + 3 : ntl);
+        if (__builtin_expect(!MS_ABL_NOFLAG_ && landed_seen < need, 0)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) :: "memory");
+            landed_seen = __builtin_amdgcn_readfirstlane(flag);
+            if (landed_seen < need) {                                         // normally long since published
+#ifdef MS_STAMP
+                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+                landed_seen = wait_landed(need);
+#ifdef MS_STAMP
+                stamp_wait += __builtin_amdgcn_s_memtime() - w0;
+                stamp_nwait += 1;
+#endif
+            }
+        }
+    };
+    auto stage = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) {
+        constexpr bool FIRST = decltype(first_c)::value;
         // tile t is complete in areg (the statement names areg so that no use of it is placed above the wait)
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]), "+v"(areg[6]), "+v"(areg[7]),
-                       "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15])
+                       "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]),
+                       "+v"(flag)
                      :: "memory");
-        // slot of tile t is free for the loader: lane 0 adds 1 to consumed[wave] (EXEC set by scalar moves: no vector instruction)
-#ifdef MS_ABL_NOEXEC
-        asm volatile("ds_add_u32 %0, %1" ::"v"(cons_addr), "v"(one) : "memory");
+        if (FIRST) {
+            // (the look at the loader's counter for this pair sits in front of the stage, in `ensure_landed`)
+        } else {
+#ifdef MS_ABL_EXEC1
+            asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(cons_addr), "v"(two) : "memory");
 #else
-        asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(cons_addr), "v"(one) : "memory");
+            asm volatile("ds_add_u32 %0, %1" ::"v"(cons_addr), "v"(two) : "memory");     // tiles t-1 and t are in registers
 #endif
+        }
         const uint32_t slot_off = (uint32_t)((t + 1) % LDR_R) * 16384u;
         float mx;
-        uint32_t flag, rbase;
-#define MS_GROUP(TT, FIRST)                                                                                   \
-        if (FIRST) { MS_MFMA_Z(out, areg[TT].x, qreg[4 * (TT) + 0]); } else { MS_MFMA(out, areg[TT].x, qreg[4 * (TT) + 0]); } \
+        uint32_t rbase;
+#define MS_GROUP(TT, ZERO_C)                                                                                  \
+        if (ZERO_C) { MS_MFMA_Z(out, areg[TT].x, qreg[4 * (TT) + 0]); } else { MS_MFMA(out, areg[TT].x, qreg[4 * (TT) + 0]); } \
         MS_MFMA(out, areg[TT].y, qreg[4 * (TT) + 1]); MS_MFMA(out, areg[TT].z, qreg[4 * (TT) + 2]); MS_MFMA(out, areg[TT].w, qreg[4 * (TT) + 3]);
 #define MS_REFILL(TT) MS_FRAG_READ(areg[2 * ((TT) - 8)], rbase, 512 * (2 * ((TT) - 8))); MS_FRAG_READ(areg[2 * ((TT) - 8) + 1], rbase, 512 * (2 * ((TT) - 8) + 1));
         MS_GROUP(0, true)
@@ -903,32 +939,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             asm volatile("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(prev[15]));
 #endif
         }
-        // The loader's counter.  A look at it costs the chain a vector instruction plus a scalar dependency (v_readfirstlane ->
-        // s_cmp -> branch: ~120 cycles in the stamps), so the wave keeps the last value it saw in a scalar register and looks
-        // again only when that no longer covers tile t+1: the wave that sets the workgroup's pace (the one that shares its SIMD
-        // with the loader) trails the loader by several tiles and looks once every few tiles.
-        // (the LDS read itself is issued every tile: it costs no vector instruction, and a branch around it would)
-        asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
-        const bool look = !MS_ABL_NOFLAG_ && (landed_seen < (uint32_t)(t + 2)) && (t + 1 < ntl);
+        if (!FIRST && !MS_ABL_NOFLAG_) asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");     // for the next pair
         MS_GROUP(5, false)
         MS_GROUP(6, false)
         asm volatile("v_add_u32 %0, %1, %2" : "=v"(rbase) : "s"(slot_off), "v"(lin0));
-        __builtin_amdgcn_sched_barrier(0);
-        if (__builtin_expect(look, 0)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(flag) :: "memory");
-            landed_seen = __builtin_amdgcn_readfirstlane(flag);
-            if (landed_seen < (uint32_t)(t + 2)) {          // normally long since published
-#ifdef MS_STAMP
-                const unsigned long long w0 = __builtin_amdgcn_s_memtime();
-#endif
-                landed_seen = wait_tile(t + 1);
-#ifdef MS_STAMP
-                stamp_wait += __builtin_amdgcn_s_memtime() - w0;
-                stamp_nwait += 1;
-#endif
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
         MS_GROUP(7, false)
         // fragments of groups already consumed <- tile t+1 (past the last tile: a stale slot, never used)
         MS_GROUP(8, false) MS_REFILL(8)
@@ -943,8 +957,14 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #undef MS_REFILL
 #undef MS_MAX3_
         __builtin_amdgcn_sched_barrier(0);
+#ifdef MS_ABL_NOCMP
+        asm volatile("" ::"v"(mx));
+        if (false) {
+            if (false) {
+#else
         if (!SAMPLE) {
             if (__builtin_expect(__ballot(mx > st.tau) != 0, 0)) {
+#endif
 #ifdef MS_STAMP
                 const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -969,7 +989,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         f32x16 acc0, acc1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
-        landed_seen = wait_tile(0);
+        landed_seen = wait_landed(1);
 #pragma unroll
         for (int f = 0; f < 16; ++f) areg[f] = *reinterpret_cast<const f32x4 *>(smem + (lin0 - ring_lds) + 512 * f);
         // every tile, the partial last one included, goes through the pipeline; its rows past
@@ -990,8 +1010,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                              "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
                              : "=&v"(hc0), "=&v"(hc1), "=&v"(hc2), "=&v"(hc3) : "v"(hp) : "memory");
             }
-            stage(t, acc0, acc1);
-            stage(t + 1, acc1, acc0);
+            ensure_landed(t);
+            stage(std::true_type{}, t, acc0, acc1);
+            stage(std::false_type{}, t + 1, acc1, acc0);
             int t2 = t;
             asm volatile("" : "+s"(t2));
             if (hist_on && (t2 & 15) == 8) {
@@ -1010,7 +1031,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             }
         }
         if (t < ntl) {
-            stage(t, acc0, acc1);
+            ensure_landed(t);
+            stage(std::true_type{}, t, acc0, acc1);
             acc0 = acc1;
         }
         // the last chain's result is read by compiler-scheduled code next: wait out the matrix pipe (the hazard

@@ -44,6 +44,11 @@ int ms_device_cu_count(void);
                                  knn_exact_faiss, dbsearch.py:213-248 */
 #define MS_MODE_COSINE_RAW 1 /* `.pt` path: F.cosine_similarity(db, q) * mask over a RAW database;
                                  search_query_against_db, dbsearch.py:75-81 */
+#define MS_MODE_COSINE_UNIT 2 /* the same `.pt` search over rows the caller has L2-normalised once with
+                                 ms_l2_normalize_rows(db, eps = 1e-8) -- cosine_similarity's own normalise-then-dot
+                                 (dbsearch.py:78) with the row half done ahead of time: no inv_norm array, the
+                                 scores leave the matrix pipe final and the scan runs at the inner-product rate;
+                                 queries are still given raw, lengths / qlen / mincov mask as in COSINE_RAW */
 
 /* F.normalize(x) in place: x[r,:] /= max(||x[r,:]||_2, eps).  dbsearch.py:303-304 (eps 1e-12);
  * also the per-operand normalisation inside F.cosine_similarity (eps 1e-8), dbsearch.py:78. */

@@ -20,6 +20,7 @@ struct ScanParams {
     const float *lengths;   // [n] or NULL
     const float *qlen;      // [nq] or NULL
     float mincov;
+    int unit_rows;          // MS_MODE_COSINE_UNIT: the rows are L2-normalised already (no inv_norm array); lengths / qlen mask as usual
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;
     const float *lb_s;      // [nq_pad] inclusive lower bound on the k-th best score (from the sample pass), or NULL
@@ -272,7 +273,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (!AUX) return;
             int64_t row = row_begin + (int64_t)t * 32 + r;
             if (row >= p.n) row = p.n - 1;
-            const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+            const float *base = ((h == 1 || p.inv_norm == nullptr) && p.lengths != nullptr) ? p.lengths : p.inv_norm;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + row),
                                              (__attribute__((address_space(3))) void *)(aux0 + (t & 3) * 64), 4, 0, 0);
         };
@@ -313,7 +314,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 // row; before the first tile (sub_row0 < row_begin, scores are -inf) any slot will do
                 const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
                 const f32x4 *ax = reinterpret_cast<const f32x4 *>(aux0 + tix * 64 + 8 * g + 4 * h);
-                inv4 = ax[0];
+                inv4 = p.unit_rows ? f32x4{1.0f, 1.0f, 1.0f, 1.0f} : ax[0];
                 len4 = ax[8];
             }
 #pragma unroll
@@ -352,7 +353,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (AUX) {
                 const int tix = (int)((sub_row0 - row_begin) >> 5) & 3;
                 const f32x4 *ax = reinterpret_cast<const f32x4 *>(aux0 + tix * 64 + 8 * g + 4 * h);
-                inv4 = ax[0];
+                inv4 = p.unit_rows ? f32x4{1.0f, 1.0f, 1.0f, 1.0f} : ax[0];
                 len4 = ax[8];
             }
 #pragma unroll
@@ -642,8 +643,15 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
 // SAMPLE: the sample pass in this form -- no lists, every lane keeps the maximum of its half of the rows of the first
 // max_tiles FULL tiles of its stream; the two maxima of a lane pair (distinct rows) are the stream's entry for the
 // bound selection (ms_sample_bound_kernel looks at values only).
-template <int KL, bool AUX, bool SAMPLE>
+// AUXM: 0 = inner-product mode; 1 = cosine mode on raw rows (1/|row| and the length mask applied to every score inside the
+// chain: ~50 more vector instructions per tile); 2 = cosine mode on UNIT rows (MS_MODE_COSINE_UNIT): the scores are final
+// as they leave the matrix pipe, and a masked row's score (+-0) can only matter to a query whose threshold is negative,
+// so the in-chain filter is the inner-product one and the mask is applied in the rare path (all of a tile's scores are
+// re-derived there); a wave with a negative threshold somewhere visits the rare path for every tile until it is gone.
+template <int KL, int AUXM, bool SAMPLE>
 __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
+    constexpr bool AUX = AUXM != 0;
+    constexpr bool SCALE_IN_CHAIN = AUXM == 1 || (AUXM == 2 && SAMPLE);      // (the sample pass needs every score final)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..3 compute, 4 loader
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             if (AUX) {
                 int64_t row = row0 + r;
                 if (row >= p.n) row = p.n - 1;
-                const float *base = (h == 1 && p.lengths != nullptr) ? p.lengths : p.inv_norm;
+                const float *base = ((h == 1 || p.inv_norm == nullptr) && p.lengths != nullptr) ? p.lengths : p.inv_norm;
                 ms_glds_v4(aux_lds + (uint32_t)(t % LDR_AUX) * 256u, base + row);
             }
             // last tile of the database: rows past the end re-read the last row (their scores are discarded)
@@ -818,14 +826,14 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         f32x4 inv4 = {1.0f, 1.0f, 1.0f, 1.0f}, len4 = {0.0f, 0.0f, 0.0f, 0.0f};
         if (AUX) {          // the group's 4 row scales and 4 row lengths: two ds_read_b128
             const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
-            inv4 = ax[0];
+            if (AUXM == 1) inv4 = ax[0];
             len4 = ax[8];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float s = acc[4 * g + j];
             if (AUX) {
-                float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8)
+                float sv = s * inv4[j];                                                      // 1 / max(|row|, 1e-8) (unit rows: 1)
                 const float mk = (qlen_eff >= len4[j] * mincov_eff) ? 1.0f : 0.0f;           // dbsearch.py:76
                 sv = sv * mk;                                                                // dbsearch.py:78
                 s = (t >= 0) ? sv : -INFINITY;     // "tile -1" of the pipeline has no aux data
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     // cosine mode: final scores of group g of the previous tile, in place (the inner-product mode needs no such step)
     auto scale_group = [&](f32x16 &acc, int t, int g) {
         const f32x4 *ax = reinterpret_cast<const f32x4 *>(auxring + (t & (LDR_AUX - 1)) * 64 + 8 * g + 4 * h);
-        const f32x4 inv4 = ax[0], len4 = ax[8];
+        const f32x4 inv4 = (AUXM == 1) ? ax[0] : f32x4{1.0f, 1.0f, 1.0f, 1.0f}, len4 = ax[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float sv = acc[4 * g + j] * inv4[j];
@@ -855,6 +863,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     uint32_t cons_addr = landed_addr + 32 + 4 * wave, two = 2, flag = 0;
     asm volatile("" : "+v"(cons_addr), "+v"(two), "+v"(flag), "+v"(landed_addr));     // kept in vector registers across the loop
     float smax = -INFINITY;                                                 // SAMPLE: this lane's best score so far
+    bool neg_tau = AUXM == 2 && (__ballot(st.tau < 0.0f) != 0);             // unit rows: some query of this wave still has a negative threshold
     uint32_t landed_seen = 0;                                               // the loader's counter as this wave last saw it (scalar)
 #ifdef MS_STAMP
     unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
@@ -911,9 +920,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #define MS_REFILL(TT) MS_FRAG_READ(areg[2 * ((TT) - 8)], rbase, 512 * (2 * ((TT) - 8))); MS_FRAG_READ(areg[2 * ((TT) - 8) + 1], rbase, 512 * (2 * ((TT) - 8) + 1));
         MS_GROUP(0, true)
         MS_GROUP(1, false)
-        if (AUX) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); __builtin_amdgcn_sched_barrier(0); }
+        if (SCALE_IN_CHAIN) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); __builtin_amdgcn_sched_barrier(0); }
         MS_GROUP(2, false)
-        if (AUX) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); __builtin_amdgcn_sched_barrier(0); }
+        if (SCALE_IN_CHAIN) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); __builtin_amdgcn_sched_barrier(0); }
         MS_GROUP(3, false)
         // the lane's maximum over the 16 scores of tile t-1 (the running maximum of the whole sample in SAMPLE mode)
 #ifdef MS_ABL_NOMAX
@@ -963,16 +972,20 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             if (false) {
 #else
         if (!SAMPLE) {
-            if (__builtin_expect(__ballot(mx > st.tau) != 0, 0)) {
+            if (__builtin_expect(__ballot(mx > st.tau) != 0 || (AUXM == 2 && neg_tau), 0)) {
 #endif
 #ifdef MS_STAMP
                 const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
                 float sc[16];
                 uint64_t m[16];
+                if (AUXM == 2) {            // unit rows: the length mask (dbsearch.py:76,78) is applied here, to the whole tile
+                    scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3);
+                }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
                 ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
+                if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
 #ifdef MS_STAMP
                 stamp_ins += __builtin_amdgcn_s_memtime() - i0;
                 stamp_nins += 1;
@@ -1028,6 +1041,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                     st.floor = fmaxf(st.floor, ms_next_below(ms_hist_edge(hg, J)));
                     st.tau = fmaxf(st.tau, st.floor);
                 }
+                if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
             }
         }
         if (t < ntl) {
@@ -1126,12 +1140,17 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    if constexpr ((KL <= 10 || (KL == 16 && !AUX)) && !UB) {    // loader-wave form: its compute waves must fit 256 registers
-                                                                  // (16-entry lists only without the cosine-mode operands)
+    if constexpr (KL <= 16 && !UB) {    // loader-wave form: its compute waves must fit 256 registers WITHOUT spills (the pinned stage
+                                        // cannot tolerate a spill of a register an LDS read is still filling): 32-entry lists do not
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
-            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUX, false>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
-            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUX, false>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+#define MS_LAUNCH_LOADER(AUXM)                                                                                           \
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUXM, false>),     \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));                 \
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUXM, false>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            if constexpr (!AUX) { MS_LAUNCH_LOADER(0) }
+            else if (sp.unit_rows) { MS_LAUNCH_LOADER(2) }
+            else { MS_LAUNCH_LOADER(1) }
+#undef MS_LAUNCH_LOADER
             MS_LAUNCH_CHECK("ms_scan_loader_kernel");
             return MS_OK;
         }
@@ -1144,11 +1163,11 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
 }
 
 // Sample pass in the loader-wave form (qwb == 4), values only: one instantiation per mode, whatever the list length.
-template <bool AUX>
+template <int AUXM>
 int launch_sample_loader_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<5, AUX, true>),
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<5, AUXM, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
-    hipLaunchKernelGGL((ms_scan_loader_kernel<5, AUX, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+    hipLaunchKernelGGL((ms_scan_loader_kernel<5, AUXM, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
     MS_LAUNCH_CHECK("ms_scan_loader_kernel (sample)");
     return MS_OK;
 }

@@ -498,9 +498,12 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     if (n >= (int64_t)0x7FFFFFFF) MS_FAIL(MS_ERR_RANGE, "ms_ip_topk: n=%lld rows per call must be < 2^31; shard the database",
                                           (long long)n);
     if ((n > 0 && db == nullptr) || q == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: NULL db / q");
-    if (mode != MS_MODE_IP_PRENORM && mode != MS_MODE_COSINE_RAW) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: unknown mode %d", mode);
+    if (mode != MS_MODE_IP_PRENORM && mode != MS_MODE_COSINE_RAW && mode != MS_MODE_COSINE_UNIT)
+        MS_FAIL(MS_ERR_ARG, "ms_ip_topk: unknown mode %d", mode);
     if (mode == MS_MODE_IP_PRENORM && (inv_norm || lengths || qlen))
-        MS_FAIL(MS_ERR_ARG, "ms_ip_topk: inv_norm / lengths / qlen are only valid in MS_MODE_COSINE_RAW");
+        MS_FAIL(MS_ERR_ARG, "ms_ip_topk: inv_norm / lengths / qlen are only valid in the cosine modes");
+    if (mode == MS_MODE_COSINE_UNIT && inv_norm)
+        MS_FAIL(MS_ERR_ARG, "ms_ip_topk: MS_MODE_COSINE_UNIT takes rows that are normalised already, not an inv_norm array");
     // (an empty shard -- a rank of a sharded search with no rows -- has NULL row arrays)
     if (n > 0 && (lengths == nullptr) != (qlen == nullptr)) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: lengths and qlen go together");
     return MS_OK;
@@ -572,6 +575,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->qn = queries_used_in_place(q, mode) ? q : reinterpret_cast<const float *>(ws + pl.off_qn);
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
+    sp->unit_rows = mode == MS_MODE_COSINE_UNIT ? 1 : 0;
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
@@ -628,7 +632,7 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
     if (!queries_used_in_place(q, mode)) {
         float *qn = reinterpret_cast<float *>(ws + pl.off_qn);
         hipLaunchKernelGGL(ms_prepare_queries_kernel, dim3((pl.nq_pad + 3) / 4), dim3(256), 0, st, q, nq, pl.nq_pad,
-                           mode == MS_MODE_COSINE_RAW ? 1 : 0, 1e-8f, qn);
+                           mode != MS_MODE_IP_PRENORM ? 1 : 0, 1e-8f, qn);
         MS_LAUNCH_CHECK("ms_prepare_queries_kernel");
     }
     if (mode == MS_MODE_COSINE_RAW && inv_norm == nullptr && n > 0) {

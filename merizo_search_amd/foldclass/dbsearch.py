@@ -54,9 +54,9 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
     """Open a database by prefix: `<db>.pt` first, else `<db>.json` (dbsearch.py:50,65).
 
     pt layout -> {'database': float32 [N,128] on the device (RAW), 'index': list of
-    (path, coords, seq), 'lengths': float32 [N], 'faiss': False, 'mdfn', 'mifn'}; this build adds
-    'inv_norm' (1/||row||, computed once on the GPU).  faiss layout -> {'database': json path,
-    'faiss': True}; the matrix is opened by dbsearch_faiss.
+    (path, coords, seq), 'lengths': float32 [N], 'faiss': False, 'mdfn', 'mifn'}; once resident on the
+    engine's device the rows are kept L2-normalised (engine.cosine_rows: the row half of cosine_similarity,
+    done once).  faiss layout -> {'database': json path, 'faiss': True}; the matrix is opened by dbsearch_faiss.
     """
     if os.path.exists(db_name + ".pt"):
         import torch
@@ -71,7 +71,7 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
         if not os.path.exists(mdfn) or not os.path.exists(mifn):
             mdfn = mifn = None
         out = {"database": raw.float().contiguous(), "index": target_index, "lengths": torch.from_numpy(lengths),
-               "faiss": False, "mdfn": mdfn, "mifn": mifn, "inv_norm": None}
+               "faiss": False, "mdfn": mdfn, "mifn": mifn}
         if engine is not None:
             _to_engine(out, engine)
         return out
@@ -83,8 +83,8 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
 
 
 def _to_engine(target_dict: dict, engine) -> None:
-    """Make this rank's rows of the `.pt` database resident on the engine's device and cache the
-    row norms.  'database' / 'lengths' / 'inv_norm' then hold rows [row_lo, row_hi) only."""
+    """Make this rank's rows of the `.pt` database resident on the engine's device, normalised once for the
+    cosine search.  'database' / 'lengths' then hold rows [row_lo, row_hi) only."""
     if target_dict.get("_engine") is engine:
         return
     rank, world = sharded.rank_world()
@@ -92,9 +92,8 @@ def _to_engine(target_dict: dict, engine) -> None:
     lo, hi = sharded.shard_bounds(n, world, rank)
     target_dict["n_rows"] = n
     target_dict["row_lo"], target_dict["row_hi"] = lo, hi
-    target_dict["database"] = engine.to_device(target_dict["database"][lo:hi])
+    target_dict["database"] = engine.cosine_rows(engine.to_device(target_dict["database"][lo:hi]))
     target_dict["lengths"] = engine.to_device(target_dict["lengths"][lo:hi])
-    target_dict["inv_norm"] = engine.row_inv_norms(target_dict["database"], 1e-8)
     target_dict["_engine"] = engine
 
 
@@ -115,9 +114,8 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
     if topk > target_dict["n_rows"]:
         raise RuntimeError("selected index k out of range")
     q = engine.to_device(emb).reshape(-1, 128)
-    scores, idx = engine.cosine_topk(target_dict["database"], q, int(topk), inv_norm=target_dict["inv_norm"],
-                                     lengths=target_dict["lengths"], qlen=engine.to_device(qlen), mincov=float(mincov),
-                                     row_offset=target_dict["row_lo"])
+    scores, idx = engine.cosine_topk(target_dict["database"], q, int(topk), lengths=target_dict["lengths"],
+                                     qlen=engine.to_device(qlen), mincov=float(mincov), row_offset=target_dict["row_lo"])
     scores, idx = sharded.exchange_and_merge(scores, idx, engine)        # no-op on one rank
     if single:
         return {"scores": scores[0], "indices": idx[0]}

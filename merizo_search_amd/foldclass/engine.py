@@ -11,8 +11,8 @@ Engine interface (tensors are torch tensors on the engine's device):
     to_device(numpy array)                                  -> tensor
     normalize_(x, eps)                                      -> x, rows L2-normalised in place
     normalized(x, eps)                                      -> new tensor, rows L2-normalised (F.normalize)
-    row_inv_norms(db, eps)                                  -> float32 [n]
-    cosine_topk(db, q, k, inv_norm, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
+    cosine_rows(db)                                         -> the resident form of a RAW `.pt` matrix for cosine_topk
+    cosine_topk(rows, q, k, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
     ip_topk(db, q, k, row_offset)                           -> (scores [nq,k], idx int64 [nq,k])
     topk_merge(scores [S,nq,k], idx [S,nq,k])               -> (scores [nq,k], idx [nq,k])
     merge_gathered(PackedExchange)                          -> (scores [nq,k], idx [nq,k])  multi-rank merge
@@ -96,9 +96,15 @@ class HipEngine:
     def row_inv_norms(self, db, eps: float = 1e-8):
         return self._ops.row_inv_norms(db, eps)
 
-    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov: float = 0.0, row_offset: int = 0):
-        return self._ops.ip_topk(db, q, k, mode=self._ops.MODE_COSINE_RAW, inv_norm=inv_norm, lengths=lengths,
-                                 qlen=qlen, mincov=mincov, row_offset=row_offset, workspace=self._ws)
+    def cosine_rows(self, db):
+        """Resident form of a RAW `.pt` matrix for cosine_topk: its rows are L2-normalised IN PLACE once
+        (x / max(|x|, 1e-8): the row half of F.cosine_similarity's normalise-both-then-dot, dbsearch.py:78), so that
+        every search runs the scan in MS_MODE_COSINE_UNIT, at the inner-product rate.  The raw matrix stays on disk."""
+        return self._ops.l2_normalize_rows_(db, 1e-8)
+
+    def cosine_topk(self, rows, q, k, lengths=None, qlen=None, mincov: float = 0.0, row_offset: int = 0):
+        return self._ops.ip_topk(rows, q, k, mode=self._ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
+                                 row_offset=row_offset, workspace=self._ws)
 
     def ip_topk(self, db, q, k, row_offset: int = 0):
         return self._ops.ip_topk(db, q, k, mode=self._ops.MODE_IP_PRENORM, row_offset=row_offset, workspace=self._ws)

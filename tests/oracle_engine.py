@@ -43,7 +43,10 @@ class OracleEngine:
         n = np.sqrt((db.numpy().astype(np.float32) ** 2).sum(1, dtype=np.float32))
         return torch.from_numpy((1.0 / np.maximum(n, eps)).astype(np.float32))
 
-    def cosine_topk(self, db, q, k, inv_norm=None, lengths=None, qlen=None, mincov=0.0, row_offset=0):
+    def cosine_rows(self, db):
+        return db              # the oracle restates the reference on the raw rows
+
+    def cosine_topk(self, db, q, k, lengths=None, qlen=None, mincov=0.0, row_offset=0):
         s, i = orc.cosine_topk(db.numpy(), q.numpy(), k, None if lengths is None else lengths.numpy(),
                                None if qlen is None else qlen.numpy(), mincov, row_offset=row_offset)
         return torch.from_numpy(s), torch.from_numpy(i)

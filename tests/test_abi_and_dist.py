@@ -136,7 +136,10 @@ def test_c_abi_argument_errors_are_reported_without_a_gpu():
     assert rc == -4 and b"shard the database" in lib.ms_last_error()
     rc = lib.ms_ip_topk(ctypes.c_void_p(16), 10, 0, ctypes.c_void_p(16), 1, 1, 0, ctypes.c_void_p(16), None, None, 0.0,
                         ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
-    assert rc == -1 and b"only valid in MS_MODE_COSINE_RAW" in lib.ms_last_error()
+    assert rc == -1 and b"only valid in the cosine modes" in lib.ms_last_error()
+    rc = lib.ms_ip_topk(ctypes.c_void_p(16), 10, 0, ctypes.c_void_p(16), 1, 1, 2, ctypes.c_void_p(16), None, None, 0.0,
+                        ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
+    assert rc == -1 and b"MS_MODE_COSINE_UNIT takes rows that are normalised already" in lib.ms_last_error()
     rc = lib.ms_ip_topk(ctypes.c_void_p(16), 10, 0, ctypes.c_void_p(16), 1, 1, 0, None, None, None, 0.0,
                         ctypes.c_void_p(16), ctypes.c_void_p(16), None, 0, None)
     assert rc == -2 and b"workspace" in lib.ms_last_error()

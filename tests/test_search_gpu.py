@@ -442,3 +442,74 @@ def test_cosine_mask_zero_ties_under_the_sample_bound(n, nq, torch_gpu):
         assert np.array_equal(i[j, :pos], i_ref[j, :pos])
         zero = s_ref[j] == 0.0
         assert np.array_equal(i[j, zero], i_ref[j, zero]) and np.array_equal(np.signbit(s[j, zero]), np.signbit(s_ref[j, zero]))
+
+
+def _cosine_unit(torch, ops, db, q, k, lengths=None, qlen=None, mincov=0.0, **kw):
+    """MS_MODE_COSINE_UNIT as the engine uses it: rows normalised once on the device (eps 1e-8), raw queries."""
+    rows = ops.l2_normalize_rows_(_dev(torch, db).clone(), 1e-8)
+    return ops.ip_topk(rows, _dev(torch, q), k, mode=ops.MODE_COSINE_UNIT, lengths=None if lengths is None else _dev(torch, lengths),
+                       qlen=None if qlen is None else _dev(torch, qlen), mincov=mincov, **kw)
+
+
+@pytest.mark.parametrize("mincov", [0.0, 0.7])
+@pytest.mark.parametrize("k", [1, 10, 100])
+def test_cosine_unit_mode_matches_reference_goldens(mincov, k, torch_gpu, golden_dir):
+    """The `.pt` search on rows normalised ahead of time (MS_MODE_COSINE_UNIT, what the engine keeps resident) against
+    the reference's search_query_against_db goldens (dbsearch.py:75-81) and against the raw-row mode."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    g = np.load(os.path.join(golden_dir, "search.npz"))
+    db, lengths = syn.raw_database(5000, seed=11)
+    q, qlen = syn.raw_queries(8, seed=12)
+    s, i = _cosine_unit(torch, ops, db, q, k, lengths, qlen, mincov)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), g[f"s_cov{mincov}_k{k}"], g[f"i_cov{mincov}_k{k}"], tol=COS_TOL)
+
+
+@pytest.mark.parametrize("n,nq,k", [(70_000, 7, 10), (70_000, 100, 10), (300_000, 256, 20), (150_000, 96, 32), (60_000, 130, 64), (3000, 70, 100)])
+def test_cosine_unit_mode_vs_oracle_all_kernel_forms(n, nq, k, torch_gpu):
+    """Few queries (row streams per wave), >= 3 query tiles (loader-wave form: mask applied in the rare path), long lists,
+    k > 64 (bounded passes): masked cosine top-k of the oracle (reference arithmetic on the raw rows)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    db, lengths = syn.raw_database(n, seed=71)
+    q, qlen = syn.raw_queries(nq, seed=72)
+    s, i = _cosine_unit(torch, ops, db, q, k, lengths, qlen, 0.7, row_offset=17)
+    s_ref, i_ref = orc.cosine_topk(db, q, k, lengths, qlen, 0.7, row_offset=17)
+    assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+    s2, i2 = _cosine_unit(torch, ops, db, q, k)                       # no mask: plain cosine
+    s_ref, i_ref = orc.cosine_topk(db, q, k, None, None, 0.0)
+    assert_topk_equivalent(s2.cpu().numpy(), i2.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+
+
+@pytest.mark.parametrize("n", [100_000, 400_000])
+@pytest.mark.parametrize("nq", [8, 96])
+def test_cosine_unit_mode_zero_ties_and_negative_thresholds(n, nq, torch_gpu):
+    """The unit-row form filters on unmasked scores and applies the mask in the rare path, which is only sound while a
+    query's threshold is >= 0: queries whose lists hold masked zeros or negative cosines (all rows masked, fewer than k
+    unmasked rows, or mostly negative scores) keep a negative threshold and must take the exact path.  Same construction
+    as the raw-row zero-tie test, plus queries pointing AWAY from every row (all cosines negative)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    k, mincov = 10, 0.7
+    db, lengths = syn.raw_database(n, seed=61 + nq)
+    db = np.abs(db)                                   # every row in the positive orthant ...
+    lengths = lengths.copy()
+    short = np.random.default_rng(5).choice(n, 7, replace=False)
+    lengths[short] = np.array([20, 20, 21, 22, 24, 25, 26], np.float32)
+    q, qlen = syn.raw_queries(nq, seed=62)
+    q = q.copy(); qlen = qlen.copy()
+    q[3::4] = -np.abs(q[3::4])                        # ... and these queries in the negative one: all cosines < 0
+    qlen[3::4] = 18.0                                 # 6 unmasked rows (negative scores), everything else masked to -0.0
+    qlen[0::4] = 3.0; qlen[1::4] = 15.0; qlen[2::4] = 17.0
+    s, i = _cosine_unit(torch, ops, db, q, k, lengths, qlen, mincov)
+    s, i = s.cpu().numpy(), i.cpu().numpy()
+    s_ref, i_ref = orc.cosine_topk(db, q, k, lengths, qlen, mincov)
+    assert_topk_equivalent(s, i, s_ref, i_ref, tol=COS_TOL)
+    zero = s_ref == 0.0
+    assert np.array_equal(i[zero], i_ref[zero]) and np.array_equal(np.signbit(s[zero]), np.signbit(s_ref[zero]))
+    assert (s_ref[3::4] <= 0).all() and (s_ref[3::4, 0] == 0).all()          # masked zeros outrank the negative cosines

@@ -259,12 +259,25 @@ struct EdgeParams {
 #endif
 };
 
+// What bounds it (tools/probes/valu_price_probe.hip, profiles/r03_valu_price_probe.log): next to v_mfma_f32_32x32x2_f32 every
+// vector instruction is ADDITIVE -- a cluster of N of them costs the matrix pipe ~8 + 4.6 N cycles (9 per v_exp / v_rcp, packed
+// fp32 at the scalar price), whichever wave of the SIMD issues them; ds_write_b128 and VMEM instructions cost 3 / 8 cycles when
+// spaced one per MFMA and 40 / 64 each in a burst.  So: (1) H is computed by the lane that needs it as its MFMA A operand --
+// lane (r, h) of wave w owns edge row 32 w + r and the k half h, exactly the fragment v_mfma_f32_32x32x2_f32 wants -- and never
+// goes through LDS (the first version wrote it with 5 ds_write_b128 per thread and stage in a burst, and needed a second
+// barrier per stage); (2) the W2 stage (40 KiB, already in B-fragment order in HBM) arrives by LDS-DMA into a ring of two
+// slots, one stage ahead, one barrier per stage; (3) the 25 memory instructions of a stage (projections of the next stage,
+// its distance weights, 10 DMA pieces) are issued one per block of 4 MFMAs; (4) the SiLU arithmetic of the next stage is ONE
+// cluster behind the stage's 160 MFMAs, kept there by a scheduling fence (hipcc would spread it through the MFMAs).
+constexpr int W_STAGE_F4 = STAGE_G * 8 * 64;                      // float4 per W2 stage (40 KiB)
+constexpr int EDGE_LDS = 2 * W_STAGE_F4 * 16;                     // two ring slots: 80 KiB per workgroup, two workgroups per CU
+
 __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    f32x4 *Hl = reinterpret_cast<f32x4 *>(smem);                    // [5 g][4 m][64 lanes]
-    f32x4 *Wl = Hl + STAGE_G * 4 * 64;                              // [5 g][8 nt][64 lanes]
+    f32x4 *Wring = reinterpret_cast<f32x4 *>(smem);                 // [2 slots][5 g][8 nt][64 lanes]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int T = blockIdx.x;
     const int d = find_segment(p.tile_pre, p.nb, T);
     const int off = p.offsets[d];
@@ -273,12 +286,53 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
     const int64_t nn = (int64_t)n * n;
     const int64_t e0 = (int64_t)tt * TILE_E;
 
-    // this thread's edge row (two threads per row, one per lane half of the A fragment)
-    const int R = tid & 127, kh = tid >> 7;
+    // this lane's edge row and k half: the A fragment of its wave's 32 x 32 x 2 MFMAs
+    const int R = 32 * wave + (lane & 31), kh = lane >> 5;
     const int64_t e = e0 + R;
     int i = 0, j = 0;
     if (e < nn) { i = (int)(e / n); j = (int)(e - (int64_t)i * n); }
     const int gi = off + i, gj = off + j;
+    const f32x4 *wc4 = reinterpret_cast<const f32x4 *>(p.prep + P_WC);
+    const f32x4 *w2f = reinterpret_cast<const f32x4 *>(p.prep + P_W2F);
+
+    // Memory instructions of the stage loop as inline asm with a SCALAR base and one 32-bit lane offset each (hipcc forms the
+    // 64-bit lane addresses with a v_lshl_add_u64 per access: 25 more vector instructions per stage, ~12 cycles apiece alone in
+    // an MFMA gap).  hipcc does not count asm loads: the waits are written out below (`wait_loads`).
+    // one 1 KiB piece of W2 stage s: pieces 10 w .. 10 w + 9 belong to wave w
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char *)smem);
+    const uint32_t voff_w = (uint32_t)(lane * sizeof(f32x4));
+    auto dma_w = [&](int s, int piece) {
+        const int pidx = wave * 10 + piece;
+        const uint64_t base = (uint64_t)(uintptr_t)w2f + ((uint64_t)s * W_STAGE_F4 + (uint64_t)pidx * 64) * sizeof(f32x4);
+        const uint32_t dst = lds0 + (uint32_t)(((s & 1) * W_STAGE_F4 + pidx * 64) * sizeof(f32x4));
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff_w), "s"(base) : "memory", "m0");
+    };
+    f32x4 pa[STAGE_G], pb[STAGE_G], pc[STAGE_G], hv[STAGE_G];
+    const uint32_t voff_a = (uint32_t)(((size_t)kh * p.total + gi) * sizeof(f32x4));
+    const uint32_t voff_b = (uint32_t)(((size_t)kh * p.total + gj) * sizeof(f32x4));
+    const uint32_t voff_c = (uint32_t)(kh * sizeof(f32x4));
+    auto load_a = [&](int s, int g) {
+        const uint64_t base = (uint64_t)(uintptr_t)p.ApT4 + (uint64_t)(2 * (STAGE_G * s + g)) * p.total * sizeof(f32x4);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pa[g]) : "v"(voff_a), "s"(base) : "memory");
+    };
+    auto load_b = [&](int s, int g) {
+        const uint64_t base = (uint64_t)(uintptr_t)p.BpT4 + (uint64_t)(2 * (STAGE_G * s + g)) * p.total * sizeof(f32x4);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pb[g]) : "v"(voff_b), "s"(base) : "memory");
+    };
+    auto load_c = [&](int s, int g) {
+        const uint64_t base = (uint64_t)(uintptr_t)wc4 + (uint64_t)(2 * (STAGE_G * s + g)) * sizeof(f32x4);
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pc[g]) : "v"(voff_c), "s"(base) : "memory");
+    };
+    auto wait_loads = [&]() {        // everything this wave has in flight: the next stage's operands and its W2 pieces
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]), "+v"(pb[4]),
+                       "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4])
+                     :: "memory");
+    };
+#pragma unroll
+    for (int pc_ = 0; pc_ < 10; ++pc_) dma_w(0, pc_);
+#pragma unroll
+    for (int g = 0; g < STAGE_G; ++g) { load_a(0, g); load_b(0, g); load_c(0, g); }
     float d2;
     {
         // rel_coors, dist = norm(rel), then dist * dist: my_egnn_nocoords.py:48-49,58
@@ -288,21 +342,20 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
         d2 = dist * dist;
     }
-    const f32x4 *wc4 = reinterpret_cast<const f32x4 *>(p.prep + P_WC);
-    const f32x4 *w2f = reinterpret_cast<const f32x4 *>(p.prep + P_W2F);
-
-    f32x4 pa[STAGE_G], pb[STAGE_G], pw[2 * STAGE_G];
-    auto issue_loads = [&](int s) {
+    wait_loads();
+    // H = SiLU(Ap_i + Bp_j + w_c * d2) of one stage, straight into the A-fragment registers
+    auto compute_h = [&]() {
 #pragma unroll
         for (int g = 0; g < STAGE_G; ++g) {
-            const int kq = 2 * (STAGE_G * s + g) + kh;
-            pa[g] = p.ApT4[(size_t)kq * p.total + gi];
-            pb[g] = p.BpT4[(size_t)kq * p.total + gj];
+            const f32x4 zsum = pa[g] + pb[g];
+            const f32x2 d2v = {d2, d2};
+            const f32x2 z01 = __builtin_elementwise_fma(f32x2{pc[g].x, pc[g].y}, d2v, f32x2{zsum.x, zsum.y});
+            const f32x2 z23 = __builtin_elementwise_fma(f32x2{pc[g].z, pc[g].w}, d2v, f32x2{zsum.z, zsum.w});
+            const f32x2 h01 = silu2_f(z01), h23 = silu2_f(z23);
+            hv[g] = f32x4{h01.x, h01.y, h23.x, h23.y};
         }
-#pragma unroll
-        for (int it = 0; it < 2 * STAGE_G; ++it) pw[it] = w2f[(size_t)s * (STAGE_G * 8 * 64) + it * 256 + tid];
     };
-    issue_loads(0);
+    compute_h();
 
     f32x16 acc[8];
 #pragma unroll
@@ -318,47 +371,41 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 #define EST(acc)
 #endif
     for (int s = 0; s < NSTAGE; ++s) {
-        // VALU phases run at raised priority: the other workgroup's wave on this SIMD is issuing MFMAs back
-        // to back and would otherwise keep most of the issue slots, although an MFMA needs 8 of every 64
-        __builtin_amdgcn_s_setprio(3);
-        // H = SiLU(Ap_i + Bp_j + w_c * d2), written straight into A-fragment order
-#pragma unroll
-        for (int g = 0; g < STAGE_G; ++g) {
-            const f32x4 wc = wc4[2 * (STAGE_G * s + g) + kh];
-            const f32x4 zsum = pa[g] + pb[g];
-            const f32x2 d2v = {d2, d2};
-            const f32x2 z01 = __builtin_elementwise_fma(f32x2{wc.x, wc.y}, d2v, f32x2{zsum.x, zsum.y});
-            const f32x2 z23 = __builtin_elementwise_fma(f32x2{wc.z, wc.w}, d2v, f32x2{zsum.z, zsum.w});
-            const f32x2 h01 = silu2_f(z01), h23 = silu2_f(z23);
-            const f32x4 hv = {h01.x, h01.y, h23.x, h23.y};
-            Hl[(g * 4 + (R >> 5)) * 64 + kh * 32 + (R & 31)] = hv;
-        }
-#pragma unroll
-        for (int it = 0; it < 2 * STAGE_G; ++it) Wl[it * 256 + tid] = pw[it];
-        EST(tH)
-        __builtin_amdgcn_s_setprio(0);
+        // W2 stage s has landed for every wave (its pieces were issued a stage ago), and every wave is done reading the other slot
         __syncthreads();
         EST(tB1)
-        if (s + 1 < NSTAGE) issue_loads(s + 1);
+        const f32x4 *Wl = Wring + (s & 1) * W_STAGE_F4 + lane;
+        const bool more = s + 1 < NSTAGE;
+        f32x4 bcur = Wl[0];
 #pragma unroll
-        for (int g = 0; g < STAGE_G; ++g) {
-            const f32x4 a = Hl[(g * 4 + wave) * 64 + lane];
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                const f32x4 b = Wl[(g * 8 + nt) * 64 + lane];
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc[nt], 0, 0, 0);
-                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc[nt], 0, 0, 0);
+        for (int blk = 0; blk < STAGE_G * 8; ++blk) {
+            const int g = blk >> 3, nt = blk & 7;
+            const f32x4 a = hv[g];
+            const f32x4 bnext = Wl[((blk + 1 < STAGE_G * 8) ? blk + 1 : blk) * 64];     // B fragment of the next block
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, bcur.x, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, bcur.y, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, bcur.z, acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, bcur.w, acc[nt], 0, 0, 0);
+            // one memory instruction of the next stage per block
+            if (more) {
+                if (blk < 5) load_a(s + 1, blk);
+                else if (blk < 10) load_b(s + 1, blk - 5);
+                else if (blk < 15) load_c(s + 1, blk - 10);
+                else if (blk < 25) dma_w(s + 1, blk - 15);
             }
+            bcur = bnext;
+            __builtin_amdgcn_sched_barrier(0);
         }
         EST(tM)
-        __syncthreads();
-        EST(tB2)
+        if (more) { wait_loads(); compute_h(); }        // (issued ~150 MFMAs ago: landed long since)
+        __builtin_amdgcn_sched_barrier(0);
+        EST(tH)
     }
 #ifdef MS_STAMP
     const unsigned long long t_loop_end = tc;
 #endif
+    const int wave_ = wave;
+    (void)wave_;
 
     __builtin_amdgcn_s_setprio(3);
     // ---- epilogue.  acc[nt][r]: edge row (r&3) + 8(r>>2) + 4(lane>>5) of this wave's 32 rows,
@@ -624,7 +671,7 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
     hipLaunchKernelGGL(ms_egnn_init_nodes_kernel, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, st, offsets, nb,
                        (int)total, pe, node_dom, h0);
     MS_LAUNCH_CHECK("ms_egnn_init_nodes_kernel");
-    const size_t edge_lds = (size_t)(STAGE_G * 4 * 64 + STAGE_G * 8 * 64) * sizeof(f32x4);
+    const size_t edge_lds = (size_t)EDGE_LDS;
     MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
     const unsigned node_blocks = (unsigned)((total + NODES_PB - 1) / NODES_PB);

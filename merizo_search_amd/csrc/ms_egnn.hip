@@ -38,8 +38,6 @@ constexpr int NSTAGE = NGRP / STAGE_G;   // 13
 constexpr int NIN = 384;
 constexpr int NHID = 256;
 constexpr int TILE_E = 128;      // edges per workgroup tile (4 waves x 32 rows)
-constexpr int NODES_PB = 16;     // nodes per workgroup in the node-level kernels
-constexpr int PROJ_NODES = 64;   // nodes per workgroup of the projection kernel
 constexpr int LAYER_FLOATS = 396165;
 
 // canonical blob offsets (state_dict order, see include/merizo_search_amd.h)
@@ -200,39 +198,56 @@ __global__ __launch_bounds__(256) void ms_egnn_init_nodes_kernel(const int32_t *
 
 // ---------------------------------------------------------------- node projections -----
 // ApT4[kq][g] (float4) = b1[4kq..] + sum_k h[g][k] W1[4kq..][k];  BpT4 likewise with W1[:,128+k], no bias.
+// NJ nodes per thread (16 NJ nodes per workgroup); a thread owns one 4-channel quad per 16 gridDim.y quads, so every pair of
+// weight float4 it loads feeds 8 NJ FMAs.  Large batches: NJ = 4, gridDim.y = 1 (each weight load reused 32 times, the quads
+// looped over).  Small batches (a query of a few domains) are latency-bound -- 6 workgroups each walking 9 x 128 dependent
+// weight loads took 132 us for 383 residues -- so they run NJ = 1 with the quads spread over gridDim.y = 9 workgroups.
+// Per output the k order of the fmaf chain is the same in every configuration.
+template <int NJ>
 __global__ __launch_bounds__(256) void ms_egnn_proj_kernel(const float *__restrict__ prep, const float *__restrict__ h,
                                                           int total, f32x4 *__restrict__ ApT4, f32x4 *__restrict__ BpT4) {
-    // 64 nodes per workgroup; a thread owns one 4-channel quad (looping over the 130 quads in steps
-    // of 16) for 4 nodes, so every pair of weight float4 it loads feeds 32 FMAs.  Per output the k
-    // order of the fmaf chain is unchanged.
-    __shared__ float hs[PROJ_NODES][DIM + 1];
-    const int g0 = blockIdx.x * PROJ_NODES;
+    constexpr int NODES = 16 * NJ;
+    __shared__ float hs[NODES][DIM + 1];
+    const int g0 = blockIdx.x * NODES;
     const int tid = threadIdx.x;
-    for (int e = tid; e < PROJ_NODES * DIM; e += 256) {
+    for (int e = tid; e < NODES * DIM; e += 256) {
         const int n = e >> 7, k = e & 127;
         hs[n][k] = (g0 + n < total) ? h[(size_t)(g0 + n) * DIM + k] : 0.0f;
     }
     __syncthreads();
-    const int n = tid & 15, cq0 = tid >> 4;
+    const int n = tid & 15, cq0 = (tid >> 4) + 16 * blockIdx.y;
     const f32x4 *w1a = reinterpret_cast<const f32x4 *>(prep + P_W1AT);
     const f32x4 *w1b = reinterpret_cast<const f32x4 *>(prep + P_W1BT);
     const f32x4 *b1 = reinterpret_cast<const f32x4 *>(prep + P_B1);
-    for (int cq = cq0; cq < KQ; cq += 16) {
-        f32x4 a[4], b[4];
+    for (int cq = cq0; cq < KQ; cq += 16 * gridDim.y) {
+        f32x4 a[NJ], b[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { a[j] = b1[cq]; b[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-#pragma unroll 4
-        for (int k = 0; k < DIM; ++k) {
-            const f32x4 wa = w1a[k * KQ + cq], wb = w1b[k * KQ + cq];
+        for (int j = 0; j < NJ; ++j) { a[j] = b1[cq]; b[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+        constexpr int PF = 8;            // weight rows fetched ahead of their use
+        f32x4 qa[PF], qb[PF];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float x = hs[n + 16 * j][k];
-                a[j].x = fmaf(x, wa.x, a[j].x); a[j].y = fmaf(x, wa.y, a[j].y); a[j].z = fmaf(x, wa.z, a[j].z); a[j].w = fmaf(x, wa.w, a[j].w);
-                b[j].x = fmaf(x, wb.x, b[j].x); b[j].y = fmaf(x, wb.y, b[j].y); b[j].z = fmaf(x, wb.z, b[j].z); b[j].w = fmaf(x, wb.w, b[j].w);
+        for (int u = 0; u < PF; ++u) { qa[u] = w1a[u * KQ + cq]; qb[u] = w1b[u * KQ + cq]; }
+        for (int k0 = 0; k0 < DIM; k0 += PF) {
+            f32x4 ca[PF], cb[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) { ca[u] = qa[u]; cb[u] = qb[u]; }
+            if (k0 + PF < DIM) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) { qa[u] = w1a[(k0 + PF + u) * KQ + cq]; qb[u] = w1b[(k0 + PF + u) * KQ + cq]; }
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const f32x4 wa = ca[u], wb = cb[u];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const float x = hs[n + 16 * j][k0 + u];
+                    a[j].x = fmaf(x, wa.x, a[j].x); a[j].y = fmaf(x, wa.y, a[j].y); a[j].z = fmaf(x, wa.z, a[j].z); a[j].w = fmaf(x, wa.w, a[j].w);
+                    b[j].x = fmaf(x, wb.x, b[j].x); b[j].y = fmaf(x, wb.y, b[j].y); b[j].z = fmaf(x, wb.z, b[j].z); b[j].w = fmaf(x, wb.w, b[j].w);
+                }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int node = g0 + n + 16 * j;
             if (node < total) {
                 ApT4[(size_t)cq * total + node] = a[j];
@@ -516,77 +531,125 @@ unsigned long long *ms_egnn_stamp_buffer() {
 }
 #endif
 
+// NB nodes per workgroup: 16 for large batches (every weight column a thread loads feeds 16 FMAs), 4 for a query of a few
+// domains (more workgroups, shorter inner work: the kernel is then a chain of L2 round trips for the weights).  The weight
+// columns are fetched PF rows ahead of their use.  Per output the fmaf chain runs over k in ascending order in every case.
+template <int NB>
 __global__ __launch_bounds__(256) void ms_egnn_node_kernel(const NodeParams p) {
-    __shared__ float xs[NODES_PB][NIN];      // [h, m_i]
-    __shared__ float hid[NODES_PB][NHID];
+    __shared__ float xs[NB][NIN];      // [h, m_i]
+    __shared__ float hid[NB][NHID];
+    constexpr int PF = NB <= 4 ? 16 : 8;
     const int tid = threadIdx.x;
-    const int g0 = blockIdx.x * NODES_PB;
-    for (int e = tid; e < NODES_PB * DIM; e += 256) {
+    const int g0 = blockIdx.x * NB;
+    for (int e = tid; e < NB * DIM; e += 256) {
         const int nd = e >> 7, k = e & 127;
         xs[nd][k] = (g0 + nd < p.total) ? p.h_in[(size_t)(g0 + nd) * DIM + k] : 0.0f;
     }
-    // m_i: sum this residue's records in record order
-    for (int nd = 0; nd < NODES_PB; ++nd) {
-        float m = 0.0f;
-        const int g = g0 + nd;
-        if (g < p.total) {
-            const int d = p.node_dom[g];
-            const int off = p.offsets[d];
-            const int n = p.offsets[d + 1] - off;
-            const int i = g - off;
-            const int C = (n + 31) / 32 + 1;
-            const int first = (int)(((int64_t)i * n) >> 5);
-            const int last = (int)(((int64_t)i * n + n - 1) >> 5);
-            const float *src = p.part + ((size_t)p.rec_pre[d] + (size_t)i * C) * MD + tid;
-            for (int q = 0; q <= last - first; ++q) m += src[(size_t)q * MD];
+    // m_i: sum this residue's records in record order (the NB residues side by side: independent loads in flight)
+    {
+        const float *src[NB];
+        int cnt[NB], cmax = 0;
+        float m[NB];
+#pragma unroll
+        for (int nd = 0; nd < NB; ++nd) {
+            const int g = g0 + nd;
+            src[nd] = p.part; cnt[nd] = 0; m[nd] = 0.0f;
+            if (g < p.total) {
+                const int d = p.node_dom[g];
+                const int off = p.offsets[d];
+                const int n = p.offsets[d + 1] - off;
+                const int i = g - off;
+                const int C = (n + 31) / 32 + 1;
+                const int first = (int)(((int64_t)i * n) >> 5);
+                const int last = (int)(((int64_t)i * n + n - 1) >> 5);
+                src[nd] = p.part + ((size_t)p.rec_pre[d] + (size_t)i * C) * MD + tid;
+                cnt[nd] = last - first + 1;
+            }
+            cmax = cnt[nd] > cmax ? cnt[nd] : cmax;
         }
-        xs[nd][DIM + tid] = m;
+        for (int q = 0; q < cmax; ++q) {
+#pragma unroll
+            for (int nd = 0; nd < NB; ++nd)
+                if (q < cnt[nd]) m[nd] += src[nd][(size_t)q * MD];
+        }
+#pragma unroll
+        for (int nd = 0; nd < NB; ++nd) xs[nd][DIM + tid] = m[nd];
     }
     __syncthreads();
-    {   // node_mlp[0] + SiLU (:31-32): thread = output channel, all 16 nodes
-        float a[NODES_PB];
+    {   // node_mlp[0] + SiLU (:31-32): thread = output channel, all NB nodes
+        float a[NB];
         const float b = p.prep[P_BN1 + tid];
 #pragma unroll
-        for (int nd = 0; nd < NODES_PB; ++nd) a[nd] = b;
+        for (int nd = 0; nd < NB; ++nd) a[nd] = b;
         const float *w = p.prep + P_WN1T + tid;
-#pragma unroll 4
-        for (int k = 0; k < NIN; ++k) {
-            const float wk = w[(size_t)k * NHID];
+        float wq[PF];
 #pragma unroll
-            for (int nd = 0; nd < NODES_PB; ++nd) a[nd] = fmaf(wk, xs[nd][k], a[nd]);
+        for (int u = 0; u < PF; ++u) wq[u] = w[(size_t)u * NHID];
+        for (int k0 = 0; k0 < NIN; k0 += PF) {
+            float wc[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) wc[u] = wq[u];
+            if (k0 + PF < NIN) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) wq[u] = w[(size_t)(k0 + PF + u) * NHID];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int nd = 0; nd < NB; ++nd) a[nd] = fmaf(wc[u], xs[nd][k0 + u], a[nd]);
         }
 #pragma unroll
-        for (int nd = 0; nd < NODES_PB; ++nd) hid[nd][tid] = silu_f(a[nd]);
+        for (int nd = 0; nd < NB; ++nd) hid[nd][tid] = silu_f(a[nd]);
     }
     __syncthreads();
     {   // node_mlp[2] + residual (:33, :72): thread = (output channel, half of the nodes)
         const int o = tid & 127, half = tid >> 7;
-        float a[NODES_PB / 2];
+        float a[NB / 2];
         const float b = p.prep[P_BN2 + o];
 #pragma unroll
-        for (int nd = 0; nd < NODES_PB / 2; ++nd) a[nd] = b;
+        for (int nd = 0; nd < NB / 2; ++nd) a[nd] = b;
         const float *w = p.prep + P_WN2T + o;
-#pragma unroll 4
-        for (int k = 0; k < NHID; ++k) {
-            const float wk = w[(size_t)k * DIM];
+        float wq[PF];
 #pragma unroll
-            for (int nd = 0; nd < NODES_PB / 2; ++nd) a[nd] = fmaf(wk, hid[half * (NODES_PB / 2) + nd][k], a[nd]);
+        for (int u = 0; u < PF; ++u) wq[u] = w[(size_t)u * DIM];
+        for (int k0 = 0; k0 < NHID; k0 += PF) {
+            float wc[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) wc[u] = wq[u];
+            if (k0 + PF < NHID) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) wq[u] = w[(size_t)(k0 + PF + u) * DIM];
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u)
+#pragma unroll
+                for (int nd = 0; nd < NB / 2; ++nd) a[nd] = fmaf(wc[u], hid[half * (NB / 2) + nd][k0 + u], a[nd]);
         }
 #pragma unroll
-        for (int nd = 0; nd < NODES_PB / 2; ++nd) {
-            const int node = half * (NODES_PB / 2) + nd;
+        for (int nd = 0; nd < NB / 2; ++nd) {
+            const int node = half * (NB / 2) + nd;
             if (g0 + node < p.total) p.h_out[(size_t)(g0 + node) * DIM + o] = a[nd] + xs[node][o];
         }
     }
 }
 
-// embed = mean over residues, in residue order (nndef_fold_egnn_embed.py:61)
+// embed = mean over residues, in residue order (nndef_fold_egnn_embed.py:61); the rows are fetched eight at a time (a loop of
+// dependent L2 round trips otherwise: 36 us for a 163-residue domain), the additions keep the residue order
 __global__ __launch_bounds__(128) void ms_egnn_pool_kernel(const float *__restrict__ h, const int32_t *__restrict__ offsets,
                                                           float *__restrict__ out) {
     const int d = blockIdx.x, c = threadIdx.x;
     const int off = offsets[d], n = offsets[d + 1] - off;
+    const float *src = h + (size_t)off * DIM + c;
     float s = 0.0f;
-    for (int i = 0; i < n; ++i) s += h[(size_t)(off + i) * DIM + c];
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(i + u) * DIM];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; i < n; ++i) s += src[(size_t)i * DIM];
     out[(size_t)d * DIM + c] = s / (float)n;
 }
 
@@ -674,12 +737,13 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
     const size_t edge_lds = (size_t)EDGE_LDS;
     MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
-    const unsigned node_blocks = (unsigned)((total + NODES_PB - 1) / NODES_PB);
     float *hin = h0, *hout = h1;
     for (int layer = 0; layer < 2; ++layer) {
         const float *lp = prep + (size_t)layer * P_LAYER;
-        hipLaunchKernelGGL(ms_egnn_proj_kernel, dim3((unsigned)((total + PROJ_NODES - 1) / PROJ_NODES)), dim3(256), 0, st, lp, hin,
-                           (int)total, ap, bp);
+        if (total > 8192)
+            hipLaunchKernelGGL(ms_egnn_proj_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, lp, hin, (int)total, ap, bp);
+        else        // a few structures: spread the quads over 9 workgroups per 16 nodes (latency, not throughput)
+            hipLaunchKernelGGL(ms_egnn_proj_kernel<1>, dim3((unsigned)((total + 15) / 16), 9), dim3(256), 0, st, lp, hin, (int)total, ap, bp);
         MS_LAUNCH_CHECK("ms_egnn_proj_kernel");
         EdgeParams ep;
         ep.prep = lp; ep.coords = coords; ep.offsets = offsets; ep.tile_pre = tile_pre; ep.rec_pre = rec_pre;
@@ -692,7 +756,8 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
         NodeParams np;
         np.prep = lp; np.h_in = hin; np.part = part; np.offsets = offsets; np.rec_pre = rec_pre; np.node_dom = node_dom;
         np.h_out = hout; np.total = (int)total;
-        hipLaunchKernelGGL(ms_egnn_node_kernel, dim3(node_blocks), dim3(256), 0, st, np);
+        if (total > 8192) hipLaunchKernelGGL(ms_egnn_node_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, np);
+        else hipLaunchKernelGGL(ms_egnn_node_kernel<4>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, np);
         MS_LAUNCH_CHECK("ms_egnn_node_kernel");
         float *t = hin; hin = hout; hout = t;
     }

@@ -210,6 +210,7 @@ class EgnnEncoder:
             torch.cuda.current_stream(self.device).synchronize()
         self.max_len = pe.shape[0]
         self._ws = None
+        self._stage = self._stage_dev = self._stage_free = None
 
     def embed(self, coords_list: Sequence[np.ndarray]):
         torch = _lib.require_gpu()
@@ -223,19 +224,39 @@ class EgnnEncoder:
         if lens.max() > self.max_len:
             raise MerizoHipError(f"embed: structure of {int(lens.max())} residues exceeds the positional table "
                                  f"({self.max_len}); the reference fails here too (nndef_fold_egnn_embed.py:12)")
-        offsets = np.zeros(nb + 1, dtype=np.int32)
-        offsets[1:] = np.cumsum(lens)
-        flat = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, 3) for c in coords_list], axis=0)
+        total = int(lens.sum())
+        # offsets and coordinates go to the device in ONE asynchronous copy out of a pinned staging buffer (two pageable
+        # copies cost a query of a few domains ~50 us of host time): [int32 offsets (nb + 1) | pad | float32 coords (total x 3)]
+        head = ((nb + 1) * 4 + 15) // 16 * 16
+        nbytes = head + total * 12
         with torch.cuda.device(self.device):
-            coords = torch.from_numpy(np.ascontiguousarray(flat)).to(self.device)
-            offs_dev = torch.from_numpy(offsets).to(self.device)
-            need = int(lib.ms_egnn_workspace_bytes(nb, int(offsets[-1]), int((lens * lens).sum())))
+            if self._stage is None or self._stage.numel() < nbytes:
+                cap = max(nbytes, 1 << 16) * 2
+                self._stage = torch.empty(cap, dtype=torch.uint8).pin_memory()
+                self._stage_dev = torch.empty(cap, dtype=torch.uint8, device=self.device)
+                self._stage_free = None
+            if self._stage_free is not None:
+                self._stage_free.synchronize()            # the previous call's copy has left the staging buffer
+            host = self._stage.numpy()
+            offsets = host[: (nb + 1) * 4].view(np.int32)
+            offsets[0] = 0
+            offsets[1:] = np.cumsum(lens)
+            flat = host[head: nbytes].view(np.float32).reshape(total, 3)
+            pos = 0
+            for c, n in zip(coords_list, lens):
+                flat[pos: pos + int(n)] = np.asarray(c, dtype=np.float32).reshape(-1, 3)
+                pos += int(n)
+            stream = torch.cuda.current_stream(self.device)
+            self._stage_dev[:nbytes].copy_(self._stage[:nbytes], non_blocking=True)
+            self._stage_free = stream.record_event()
+            offs_ptr = self._stage_dev.data_ptr()
+            coords_ptr = offs_ptr + head
+            need = int(lib.ms_egnn_workspace_bytes(nb, total, int((lens * lens).sum())))
             if self._ws is None or self._ws.numel() < need:
                 self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             out = torch.empty((nb, DIM), dtype=torch.float32, device=self.device)
-            check(lib.ms_egnn_embed(ptr(self.prepared), ptr(self.pe), self.max_len, ptr(coords), ptr(offs_dev),
-                                    offsets.ctypes.data, nb, ptr(out), ptr(self._ws), self._ws.numel(),
-                                    torch.cuda.current_stream(self.device).cuda_stream), "ms_egnn_embed")
-            # `offsets` (host) is only read during the call; coords/offs_dev stay alive until the
-            # stream has consumed them because torch's caching allocator is stream-ordered.
+            # (`offsets` in the pinned buffer is only read by the host during the call itself)
+            check(lib.ms_egnn_embed(ptr(self.prepared), ptr(self.pe), self.max_len, coords_ptr, offs_ptr,
+                                    offsets.ctypes.data, nb, ptr(out), ptr(self._ws), self._ws.numel(), stream.cuda_stream),
+                  "ms_egnn_embed")
         return out

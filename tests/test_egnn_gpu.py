@@ -87,3 +87,21 @@ def test_thousand_domain_batch_properties(encoder):
     assert np.array_equal(e[perm], e2)
     for i in (0, 17, 511, 999):
         assert np.array_equal(encoder.embed([coords[i]]).cpu().numpy()[0], e[i])
+
+
+@pytest.mark.parametrize("case", ["M0", "walk97", "walk292"])
+def test_embedding_with_a_large_distance_weight_saturated_silu(case, golden_dir):
+    """d2_scale = 1.0: the squared-distance column of edge_mlp.0.weight at full scale drives the first SiLU to pre-activations
+    of +-1e2..1e3: v_exp_f32 overflows to +inf on one side and underflows on the other, v_rcp_f32 must turn that
+    into exactly 0 / 1.  Against the reference's goldens (oracle/gen_golden_d2.py) and the oracle."""
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import weights as W
+    from oracle import oracle as orc
+    g = np.load(os.path.join(golden_dir, "egnn_d2.npz"))
+    weights, pe = W.pack_state_dict(W.synthetic_state_dict(0, d2_scale=float(g["d2_scale"])))
+    enc = ops.EgnnEncoder(weights, pe, "cuda:0")
+    coords = g[f"coords_{case}"]
+    e = enc.embed([coords]).cpu().numpy()[0]
+    assert np.isfinite(e).all()
+    _check(e, g[f"emb_{case}"])
+    _check(e, orc.egnn_embed(weights, pe, [coords])[0])

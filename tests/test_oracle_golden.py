@@ -157,3 +157,16 @@ def test_torch_cpu_baseline_legs_are_the_reference_arithmetic(golden_dir):
     dbn = orc.l2_normalize_rows(db, 1e-12)
     fs, fi = tb.faiss_path_search(torch.from_numpy(dbn), torch.from_numpy(q), 10, block=777)
     assert_topk_equivalent(fs.numpy(), fi.numpy(), s["s_prenorm_k10"], s["i_prenorm_k10"], tol=3e-7)
+
+
+@pytest.mark.parametrize("case", ["M0", "walk97", "walk292"])
+def test_oracle_egnn_with_a_large_distance_weight(case, golden_dir):
+    """The C restatement against the reference with the distance column of edge_mlp.0.weight at full scale (saturated SiLU:
+    oracle/gen_golden_d2.py)."""
+    from merizo_search_amd.foldclass import weights as W
+    from oracle import oracle as orc
+    g = np.load(os.path.join(golden_dir, "egnn_d2.npz"))
+    weights, pe = W.pack_state_dict(W.synthetic_state_dict(0, d2_scale=float(g["d2_scale"])))
+    e = orc.egnn_embed(weights, pe, [g[f"coords_{case}"]])[0]
+    ref = g[f"emb_{case}"]
+    assert np.abs(e - ref).max() <= 1e-5 * np.abs(ref).max()

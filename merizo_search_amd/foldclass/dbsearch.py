@@ -61,7 +61,10 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
     if os.path.exists(db_name + ".pt"):
         import torch
 
-        raw = torch.load(db_name + ".pt", map_location="cpu", weights_only=True)
+        try:        # memory-mapped: under N ranks every rank then reads only the pages of ITS rows (_to_engine slices first)
+            raw = torch.load(db_name + ".pt", map_location="cpu", weights_only=True, mmap=True)
+        except (RuntimeError, TypeError, ValueError):       # (an archive written in the legacy, non-zip format)
+            raw = torch.load(db_name + ".pt", map_location="cpu", weights_only=True)
         with open(db_name + ".index", "rb") as handle:
             target_index = pickle.load(handle)
         assert len(target_index) == raw.size(0)
@@ -70,7 +73,7 @@ def read_database(db_name: str, device=None, engine=None) -> dict:
         mifn = mdfn + ".index"
         if not os.path.exists(mdfn) or not os.path.exists(mifn):
             mdfn = mifn = None
-        out = {"database": raw.float().contiguous(), "index": target_index, "lengths": torch.from_numpy(lengths),
+        out = {"database": raw, "index": target_index, "lengths": torch.from_numpy(lengths),
                "faiss": False, "mdfn": mdfn, "mifn": mifn}
         if engine is not None:
             _to_engine(out, engine)
@@ -92,7 +95,7 @@ def _to_engine(target_dict: dict, engine) -> None:
     lo, hi = sharded.shard_bounds(n, world, rank)
     target_dict["n_rows"] = n
     target_dict["row_lo"], target_dict["row_hi"] = lo, hi
-    target_dict["database"] = engine.cosine_rows(engine.to_device(target_dict["database"][lo:hi]))
+    target_dict["database"] = engine.cosine_rows(engine.to_device(target_dict["database"][lo:hi].float().contiguous()))
     target_dict["lengths"] = engine.to_device(target_dict["lengths"][lo:hi])
     target_dict["_engine"] = engine
 

@@ -896,12 +896,15 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     };
     auto stage = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) {
         constexpr bool FIRST = decltype(first_c)::value;
-        // tile t is complete in areg (the statement names areg so that no use of it is placed above the wait)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]), "+v"(areg[6]), "+v"(areg[7]),
-                       "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]),
-                       "+v"(flag)
-                     :: "memory");
+        // Tile t is in areg (the statement names areg so that no use of it is placed above the wait) -- except, where the
+        // chain's gaps hold no other LDS reads (LATE_WAIT), its last four fragments: they were requested behind the last
+        // MFMAs of the previous chain, are not needed before group 12 of this one, and waiting for them here would expose
+        // their LDS latency (~50 cycles per tile).  LDS operations return in order, so "all but the 4 youngest" is exact.
+        constexpr bool LATE_WAIT = !SCALE_IN_CHAIN;
+#define MS_AREG_ALL "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]), "+v"(areg[6]), "+v"(areg[7]), \
+                    "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15])
+        if (LATE_WAIT) asm volatile("s_waitcnt lgkmcnt(4)" : MS_AREG_ALL, "+v"(flag) :: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : MS_AREG_ALL, "+v"(flag) :: "memory");
         if (FIRST) {
             // (the look at the loader's counter for this pair sits in front of the stage, in `ensure_landed`)
         } else {
@@ -958,6 +961,12 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         MS_GROUP(9, false) MS_REFILL(9)
         MS_GROUP(10, false) MS_REFILL(10)
         MS_GROUP(11, false) MS_REFILL(11)
+        if (LATE_WAIT) {    // fragments 12..15 of THIS tile: everything older than this stage's own LDS operations (8 refill reads; the
+                            // second stage of a pair also issued its counter add and re-read) has returned
+            if (FIRST) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]) :: "memory");
+            else if (MS_ABL_NOFLAG_) asm volatile("s_waitcnt lgkmcnt(9)" : "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]) :: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(areg[12]), "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]) :: "memory");
+        }
         MS_GROUP(12, false) MS_REFILL(12)
         MS_GROUP(13, false) MS_REFILL(13)
         MS_GROUP(14, false) MS_REFILL(14)
@@ -965,6 +974,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #undef MS_GROUP
 #undef MS_REFILL
 #undef MS_MAX3_
+#undef MS_AREG_ALL
         __builtin_amdgcn_sched_barrier(0);
 #ifdef MS_ABL_NOCMP
         asm volatile("" ::"v"(mx));

@@ -31,6 +31,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <mutex>
+
 thread_local char ms_err_buf[512] = "";
 
 // ------------------------------------------------------------------ normalisation ------
@@ -413,6 +415,28 @@ int sample_min_queries_setting() {
     return v;
 }
 
+// Histogram counters of the shared bound (ScanHist) must be zero when a scan starts.  ms_sample_bound_kernel zeroes them
+// (every ms_ip_topk / ms_ip_topk_prepare); a staged ms_ip_topk_scan that does not directly follow a prepare on the same
+// workspace and shape (the same workspace scanned twice in a row) gets a hipMemsetAsync in front of it.  The record below is
+// only that optimisation's bookkeeping: per workspace pointer, did the last staged call leave the counters clean?
+struct HistClean { const void *ws; int64_t n; int nq, k; bool clean; };
+HistClean g_hist_clean[16];
+int g_hist_clean_next = 0;
+std::mutex g_hist_clean_mutex;
+bool hist_take_clean(const void *ws, int64_t n, int nq, int k) {         // -> were they clean?  (they are dirty afterwards)
+    std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
+    for (HistClean &e : g_hist_clean)
+        if (e.ws == ws && e.n == n && e.nq == nq && e.k == k) { const bool c = e.clean; e.clean = false; return c; }
+    return false;
+}
+void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
+    std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
+    for (HistClean &e : g_hist_clean)
+        if (e.ws == ws) { e.n = n; e.nq = nq; e.k = k; e.clean = true; return; }
+    g_hist_clean[g_hist_clean_next] = HistClean{ws, n, nq, k, true};
+    g_hist_clean_next = (g_hist_clean_next + 1) % 16;
+}
+
 int hist_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_SHARED_BOUND"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = no shared bound
@@ -711,7 +735,9 @@ int ms_ip_topk_prepare(const float *db, int64_t n, const float *q, int nq, int k
     ScanParams sp;
     rc = prepare_scan(pl, db, n, q, nq, mode, inv_norm, lengths, qlen, mincov, (char *)workspace, (hipStream_t)stream, &sp);
     if (rc) return rc;
-    return run_prepass(pl, &sp, nq, (char *)workspace, (hipStream_t)stream);
+    rc = run_prepass(pl, &sp, nq, (char *)workspace, (hipStream_t)stream);
+    if (rc == MS_OK && sp.hist != nullptr) hist_mark_clean(workspace, n, nq, k);      // (ms_sample_bound_kernel zeroed the counters)
+    return rc;
 }
 
 int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, const float *inv_norm,
@@ -733,7 +759,8 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
             sp.hist = reinterpret_cast<uint32_t *>(ws + pl.off_hist);
             sp.hstep = reinterpret_cast<const float *>(ws + pl.off_hstep);
             // the counters must start at zero for EVERY scan (a second scan after one prepare would otherwise count rows twice)
-            MS_HIP_CHECK(hipMemsetAsync(sp.hist, 0, (size_t)pl.nq_pad * 16 * sizeof(uint32_t), (hipStream_t)stream));
+            if (!hist_take_clean(workspace, n, nq, k))
+                MS_HIP_CHECK(hipMemsetAsync(sp.hist, 0, (size_t)pl.nq_pad * 16 * sizeof(uint32_t), (hipStream_t)stream));
         }
     }
     return launch_scan(pl, sp, (hipStream_t)stream);

@@ -513,3 +513,22 @@ def test_cosine_unit_mode_zero_ties_and_negative_thresholds(n, nq, torch_gpu):
     zero = s_ref == 0.0
     assert np.array_equal(i[zero], i_ref[zero]) and np.array_equal(np.signbit(s[zero]), np.signbit(s_ref[zero]))
     assert (s_ref[3::4] <= 0).all() and (s_ref[3::4, 0] == 0).all()          # masked zeros outrank the negative cosines
+
+
+def test_staged_scan_twice_after_one_prepare_is_still_exact(torch_gpu):
+    """ms_ip_topk_prepare leaves the shared-bound counters zeroed for ONE scan; a second ms_ip_topk_scan on the same workspace
+    without a new prepare must not count rows twice (the library zeroes the counters itself then)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, nq, k = 300_000, 128, 10
+    db, q = _norm_db(n, seed=5), _norm_db(nq, seed=6)
+    d, dq = _dev(torch, db), _dev(torch, q)
+    ws = ops.TopKWorkspace(d.device).get(n, nq, k)
+    out_s = torch.empty(nq, k, device="cuda"); out_i = torch.empty(nq, k, dtype=torch.int64, device="cuda")
+    s_ref, i_ref = orc.ip_topk(db, q, k, order=1)
+    ops.ip_topk_prepare(d, dq, k, ws)
+    for _ in range(3):
+        ops.ip_topk_scan(d, dq, k, ws)
+        ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+        assert np.array_equal(out_i.cpu().numpy(), i_ref) and np.array_equal(out_s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))

@@ -49,6 +49,10 @@ int ms_device_cu_count(void);
                                  (dbsearch.py:78) with the row half done ahead of time: no inv_norm array, the
                                  scores leave the matrix pipe final and the scan runs at the inner-product rate;
                                  queries are still given raw, lengths / qlen / mincov mask as in COSINE_RAW */
+#define MS_MODE_IP_NORMQ 3   /* the faiss path with its query normalisation fused in: q is RAW, F.normalize(q) (eps 1e-12,
+                                 dbsearch.py:303-304) is applied inside the call (for up to 64 queries inside the scan launch
+                                 itself), then knn_exact_faiss as in MS_MODE_IP_PRENORM.  Bit-identical to
+                                 ms_l2_normalize_rows_to + MS_MODE_IP_PRENORM */
 
 /* F.normalize(x) in place: x[r,:] /= max(||x[r,:]||_2, eps).  dbsearch.py:303-304 (eps 1e-12);
  * also the per-operand normalisation inside F.cosine_similarity (eps 1e-8), dbsearch.py:78. */

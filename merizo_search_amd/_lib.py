@@ -17,6 +17,7 @@ CSRC = os.path.join(_PKG, "csrc")
 MODE_IP_PRENORM = 0
 MODE_COSINE_RAW = 1
 MODE_COSINE_UNIT = 2
+MODE_IP_NORMQ = 3
 DIM = 128
 
 

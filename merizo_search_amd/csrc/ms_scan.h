@@ -20,6 +20,8 @@ struct ScanParams {
     const float *lengths;   // [n] or NULL
     const float *qlen;      // [nq] or NULL
     float mincov;
+    float qnorm_eps;        // > 0: qn is the caller's RAW query array; every wave L2-normalises its query tile itself (x / max(|x|, eps),
+                            //      the arithmetic of ms_normalize_rows_kernel) -- the kernels for 1-2 query tiles only
     int unit_rows;          // MS_MODE_COSINE_UNIT: the rows are L2-normalised already (no inv_norm array); lengths / qlen mask as usual
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;
@@ -27,6 +29,13 @@ struct ScanParams {
     uint32_t *hist;         // [nq_pad][16] candidates counted per score bucket during the full pass (loader-wave form), or NULL
     const float *hstep;     // [nq_pad] bucket width of a query (bucket j starts at lb + j * step); 0 = no histogram for it
     int max_tiles;          // > 0: sample pass, every stream stops after this many tiles
+    // A handful of queries (1-2 query tiles, ms_ip_topk only): the LAST workgroup of a query group to finish merges the lists
+    // inside the scan launch -- final results straight into fin_s / fin_i, no merge launch (NULL: off)
+    float *fin_s;
+    int64_t *fin_i;
+    int64_t fin_row_offset;
+    int fin_stride;
+    uint32_t *ticket;       // [n_qgroups] arrival counters, zero between launches (the last arriver resets its counter)
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
     int rows_per_stream;    // multiple of 32
@@ -47,6 +56,93 @@ __device__ __forceinline__ uint32_t ms_xor32_u(uint32_t x, int h) {
     return h ? r[0] : r[1];
 }
 __device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_float(ms_xor32_u(__float_as_uint(x), h)); }
+
+// Head-advance merge of the P partial lists (rank-major [k][P], each sorted best first) of query q by ONE wave: the [k][P]
+// block is staged in `ent` (LDS, k * P entries), then k rounds of "best list head wins and its list advances" -- a wave-level
+// arg-max per round, no block barrier, no pool.  Used by ms_head_merge_kernel (one wave per query) and, for a handful of
+// queries, by the last workgroup of the scan launch itself (ms_scan_body).
+template <int PER>      // lists per lane: P <= 64 * PER
+__device__ __forceinline__ void ms_head_merge_wave(uint2 *ent, const float *part_s, const uint32_t *part_i, int P, int k,
+                                                   int64_t row_offset, float *out_s, int64_t *out_i, int out_stride, int out_col0,
+                                                   float *ub_s, uint32_t *ub_i, int q, int lane) {
+    const float *ps = part_s + (size_t)q * k * P;
+    const uint32_t *pi = part_i + (size_t)q * k * P;
+#pragma unroll 8
+    for (int e = lane; e < k * P; e += 64) ent[e] = make_uint2(__float_as_uint(ps[e]), pi[e]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its own LDS writes are in order; no barrier)
+    float hs[PER];
+    uint32_t hi[PER];
+    int dep[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int pp = lane + 64 * u;
+        hs[u] = -INFINITY; hi[u] = MS_IDX_NONE; dep[u] = 0;
+        if (pp < P) { const uint2 e = ent[pp]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
+    }
+    const size_t o0 = (size_t)q * out_stride + out_col0;
+    for (int round = 0; round < k; ++round) {
+        float bs = hs[0];
+        uint32_t bi = hi[0];
+        int bu = 0;
+#pragma unroll
+        for (int u = 1; u < PER; ++u)
+            if (ms_better(hs[u], hi[u], bs, bi)) { bs = hs[u]; bi = hi[u]; bu = u; }
+        // wave arg-max: 4 DPP steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror, row
+        // mirror: max is idempotent, so mirrors all-reduce as well as a butterfly), then the 4 row
+        // results through SGPRs -- no LDS-crossbar shuffles in the round
+        float ws = bs;
+        uint32_t wi = bi;
+#define MS_DPP_STEP(CTRL)                                                                                         \
+        {                                                                                                         \
+            const float os = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ws), CTRL, 0xF, 0xF, false)); \
+            const uint32_t oi = __builtin_amdgcn_update_dpp(0u, wi, CTRL, 0xF, 0xF, false);                       \
+            if (ms_better(os, oi, ws, wi)) { ws = os; wi = oi; }                                                  \
+        }
+        MS_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
+        MS_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
+        MS_DPP_STEP(0x141)     // row_half_mirror
+        MS_DPP_STEP(0x140)     // row_mirror
+#undef MS_DPP_STEP
+        {
+            float rs = ms_readlane_f(ws, 0);
+            uint32_t ri = ms_readlane_u(wi, 0);
+#pragma unroll
+            for (int row = 1; row < 4; ++row) {
+                const float os = ms_readlane_f(ws, 16 * row);
+                const uint32_t oi = ms_readlane_u(wi, 16 * row);
+                if (ms_better(os, oi, rs, ri)) { rs = os; ri = oi; }
+            }
+            ws = rs; wi = ri;
+        }
+        if (wi == MS_IDX_NONE) {                                // every list is exhausted: pad the tail
+            if (lane == 0) {
+                for (int r2 = round; r2 < k; ++r2) { out_s[o0 + r2] = -INFINITY; out_i[o0 + r2] = -1; }
+                if (ub_s != nullptr) { ub_s[q] = -INFINITY; ub_i[q] = MS_IDX_NONE; }
+            }
+            break;
+        }
+        if (lane == 0) {
+            out_s[o0 + round] = ws;
+            out_i[o0 + round] = row_offset + (int64_t)wi;
+            if (round == k - 1 && ub_s != nullptr) { ub_s[q] = ws; ub_i[q] = wi; }
+        }
+        if (bi == wi) {                                         // rows are unique across lists: exactly one lane
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                if (u != bu) continue;
+                const int d = ++dep[u];
+                hs[u] = -INFINITY; hi[u] = MS_IDX_NONE;
+                if (d < k) { const uint2 e = ent[(size_t)d * P + lane + 64 * u]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ float ms_wave_sum_xor(float v) {       // the butterfly of ms_normalize_rows_kernel (same order, same bits)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
 
 // One wave = one (query tile, row stream) pair, one wave per SIMD; waves never synchronise
 // with each other inside the scan.  The loop over 32-row tiles is software-pipelined around
@@ -242,7 +338,32 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 
         // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
         float qreg[64];
-        {
+        if (p.qnorm_eps > 0.0f) {
+            // MS_MODE_IP_NORMQ with 1-2 query tiles: F.normalize of the raw queries (dbsearch.py:303-304) inside the scan launch.
+            // The wave normalises the rows of its tile one by one exactly as ms_normalize_rows_kernel does (float2 per lane, the
+            // same butterfly sum, sqrt, max, divide: the same bits) into its own second tile slot, which no DMA has touched yet,
+            // and reads its B operand back from there.
+            float *qn_lds = reinterpret_cast<float *>(slot0 + 1024);
+            const int rows = (p.nq - qtile * 32) < 32 ? (p.nq - qtile * 32) : 32;
+            for (int row = 0; row < 32; ++row) {
+                float2 v = make_float2(0.0f, 0.0f);
+                if (row < rows) {
+                    v = *(reinterpret_cast<const float2 *>(p.qn + (size_t)(qtile * 32 + row) * MS_DIM) + lane);
+                    const float ss = ms_wave_sum_xor(v.x * v.x + v.y * v.y);
+                    const float nrm = fmaxf(sqrtf(ss), p.qnorm_eps);
+                    v.x = v.x / nrm;
+                    v.y = v.y / nrm;
+                }
+                *(reinterpret_cast<float2 *>(qn_lds + row * MS_DIM) + lane) = v;
+            }
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(qn_lds + r * MS_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 v = src[t];
+                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
             // p.qn may be the caller's own [nq,128] array (inner-product mode): rows past nq read as zeros
             const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
 #pragma unroll
@@ -560,6 +681,38 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const size_t o = ((size_t)(qt * 32 + pq) * p.k + rank) * p.P + sgroup;
         p.part_s[o] = __uint_as_float(v.x);
         p.part_i[o] = v.y;
+    }
+    if (!MAXONLY && p.fin_s != nullptr) {
+        // One launch per search for a handful of queries: the last workgroup of this query group to get here merges.
+        // Hand-off by the book (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, workgroup
+        // barrier, ONE lane releases at agent scope and takes a ticket; the last arriver acquires, then everybody loads.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        volatile uint32_t *last_flag = reinterpret_cast<volatile uint32_t *>(smem);       // (the list area is free again)
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t tk = __hip_atomic_fetch_add(p.ticket + qg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = tk == (uint32_t)p.n_sgroups - 1u;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            *last_flag = last ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool i_am_last = *last_flag != 0u;
+        __syncthreads();
+        if (i_am_last) {
+            uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)wave * 33792);            // 33 KiB per wave: k * P <= 4224 entries
+            for (int lq = wave; lq < p.qwb * 32; lq += 4) {
+                const int qq = qg * p.qwb * 32 + lq;
+                if (qq >= p.nq) break;
+                ms_head_merge_wave<4>(ent, p.part_s, p.part_i, p.P, p.k, p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0, nullptr,
+                                      nullptr, qq, lane);
+            }
+            if (tid == 0) p.ticket[qg] = 0u;             // (visible to the next launch: kernel boundary)
+        }
     }
 }
 
@@ -1132,7 +1285,7 @@ struct ScanPlan {
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
     size_t lds_bytes;
     // workspace carve (byte offsets)
-    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, total;
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, off_ticket, total;
 };
 
 inline int loader_wave_setting() {

@@ -194,79 +194,8 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
                                                           int64_t row_offset, float *out_s, int64_t *out_i,
                                                           int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint2 *ent = reinterpret_cast<uint2 *>(smem);               // [k][P]
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const float *ps = part_s + (size_t)q * k * P;
-    const uint32_t *pi = part_i + (size_t)q * k * P;
-#pragma unroll 8
-    for (int e = lane; e < k * P; e += 64) ent[e] = make_uint2(__float_as_uint(ps[e]), pi[e]);
-    __syncthreads();
-    float hs[PER];
-    uint32_t hi[PER];
-    int dep[PER];
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-        const int pp = lane + 64 * u;
-        hs[u] = -INFINITY; hi[u] = MS_IDX_NONE; dep[u] = 0;
-        if (pp < P) { const uint2 e = ent[pp]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
-    }
-    const size_t o0 = (size_t)q * out_stride + out_col0;
-    for (int round = 0; round < k; ++round) {
-        float bs = hs[0];
-        uint32_t bi = hi[0];
-        int bu = 0;
-#pragma unroll
-        for (int u = 1; u < PER; ++u)
-            if (ms_better(hs[u], hi[u], bs, bi)) { bs = hs[u]; bi = hi[u]; bu = u; }
-        // wave arg-max: 4 DPP steps inside each row of 16 lanes (xor 1, xor 2, half-row mirror, row
-        // mirror: max is idempotent, so mirrors all-reduce as well as a butterfly), then the 4 row
-        // results through SGPRs -- no LDS-crossbar shuffles in the round
-        float ws = bs;
-        uint32_t wi = bi;
-#define MS_DPP_STEP(CTRL)                                                                                         \
-        {                                                                                                         \
-            const float os = __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(ws), CTRL, 0xF, 0xF, false)); \
-            const uint32_t oi = __builtin_amdgcn_update_dpp(0u, wi, CTRL, 0xF, 0xF, false);                       \
-            if (ms_better(os, oi, ws, wi)) { ws = os; wi = oi; }                                                  \
-        }
-        MS_DPP_STEP(0xB1)      // quad_perm [1,0,3,2]
-        MS_DPP_STEP(0x4E)      // quad_perm [2,3,0,1]
-        MS_DPP_STEP(0x141)     // row_half_mirror
-        MS_DPP_STEP(0x140)     // row_mirror
-#undef MS_DPP_STEP
-        {
-            float rs = ms_readlane_f(ws, 0);
-            uint32_t ri = ms_readlane_u(wi, 0);
-#pragma unroll
-            for (int row = 1; row < 4; ++row) {
-                const float os = ms_readlane_f(ws, 16 * row);
-                const uint32_t oi = ms_readlane_u(wi, 16 * row);
-                if (ms_better(os, oi, rs, ri)) { rs = os; ri = oi; }
-            }
-            ws = rs; wi = ri;
-        }
-        if (wi == MS_IDX_NONE) {                                // every list is exhausted: pad the tail
-            if (lane == 0) {
-                for (int r2 = round; r2 < k; ++r2) { out_s[o0 + r2] = -INFINITY; out_i[o0 + r2] = -1; }
-                if (ub_s != nullptr) { ub_s[q] = -INFINITY; ub_i[q] = MS_IDX_NONE; }
-            }
-            break;
-        }
-        if (lane == 0) {
-            out_s[o0 + round] = ws;
-            out_i[o0 + round] = row_offset + (int64_t)wi;
-            if (round == k - 1 && ub_s != nullptr) { ub_s[q] = ws; ub_i[q] = wi; }
-        }
-        if (bi == wi) {                                         // rows are unique across lists: exactly one lane
-#pragma unroll
-            for (int u = 0; u < PER; ++u) {
-                if (u != bu) continue;
-                const int d = ++dep[u];
-                hs[u] = -INFINITY; hi[u] = MS_IDX_NONE;
-                if (d < k) { const uint2 e = ent[(size_t)d * P + lane + 64 * u]; hs[u] = __uint_as_float(e.x); hi[u] = e.y; }
-            }
-        }
-    }
+    ms_head_merge_wave<PER>(reinterpret_cast<uint2 *>(smem), part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0,
+                            ub_s, ub_i, blockIdx.x, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ sample bound -------
@@ -437,6 +366,24 @@ void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
     g_hist_clean_next = (g_hist_clean_next + 1) % 16;
 }
 
+// Arrival counters of the in-launch merge: zeroed once per workspace (the last arriver leaves its counter at zero), which this
+// table remembers; a workspace it does not know gets a hipMemsetAsync.
+const void *g_ticket_ready[32];
+int g_ticket_ready_next = 0;
+bool ticket_ready(const void *ticket_area) {
+    std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
+    for (const void *e : g_ticket_ready)
+        if (e == ticket_area) return true;
+    g_ticket_ready[g_ticket_ready_next] = ticket_area;
+    g_ticket_ready_next = (g_ticket_ready_next + 1) % 32;
+    return false;
+}
+int fused_merge_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_FUSED_MERGE_MAX_NQ"); v = e ? atoi(e) : 8; }      // diagnostics: 0 = always a merge launch
+    return v;
+}
+
 int hist_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_SHARED_BOUND"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = no shared bound
@@ -511,6 +458,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.off_scr_i = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(int64_t), 256);
     pl.off_hist = off;    off += ms_align_up((size_t)pl.nq_pad * 16 * sizeof(uint32_t), 256);
     pl.off_hstep = off;   off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
+    pl.off_ticket = off;  off += ms_align_up((size_t)(pl.n_qgroups > 64 ? pl.n_qgroups : 64) * sizeof(uint32_t), 256);
     pl.total = off;
     return pl;
 }
@@ -522,9 +470,9 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
     if (n >= (int64_t)0x7FFFFFFF) MS_FAIL(MS_ERR_RANGE, "ms_ip_topk: n=%lld rows per call must be < 2^31; shard the database",
                                           (long long)n);
     if ((n > 0 && db == nullptr) || q == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk: NULL db / q");
-    if (mode != MS_MODE_IP_PRENORM && mode != MS_MODE_COSINE_RAW && mode != MS_MODE_COSINE_UNIT)
+    if (mode != MS_MODE_IP_PRENORM && mode != MS_MODE_COSINE_RAW && mode != MS_MODE_COSINE_UNIT && mode != MS_MODE_IP_NORMQ)
         MS_FAIL(MS_ERR_ARG, "ms_ip_topk: unknown mode %d", mode);
-    if (mode == MS_MODE_IP_PRENORM && (inv_norm || lengths || qlen))
+    if ((mode == MS_MODE_IP_PRENORM || mode == MS_MODE_IP_NORMQ) && (inv_norm || lengths || qlen))
         MS_FAIL(MS_ERR_ARG, "ms_ip_topk: inv_norm / lengths / qlen are only valid in the cosine modes");
     if (mode == MS_MODE_COSINE_UNIT && inv_norm)
         MS_FAIL(MS_ERR_ARG, "ms_ip_topk: MS_MODE_COSINE_UNIT takes rows that are normalised already, not an inv_norm array");
@@ -589,19 +537,27 @@ extern "C" int ms_debug_stamps(unsigned long long *host, int words) {
 
 // Inner-product mode uses the queries as given: the scan kernels read the caller's array directly
 // (no padded copy, one launch less per batch) when it is 16-byte aligned.
-bool queries_used_in_place(const float *q, int mode) { return mode == MS_MODE_IP_PRENORM && ((uintptr_t)q & 15) == 0; }
+// ... and so does MS_MODE_IP_NORMQ when the batch runs in the kernels for 1-2 query tiles, whose waves normalise their
+// own query tile (ScanParams::qnorm_eps); larger batches get the prepared copy (ms_prepare_queries_kernel, eps 1e-12).
+bool queries_used_in_place(const float *q, int mode, const ScanPlan &pl) {
+    if (mode == MS_MODE_IP_PRENORM) return ((uintptr_t)q & 15) == 0;
+    if (mode == MS_MODE_IP_NORMQ) return pl.qwb < 4 && ((uintptr_t)q & 7) == 0;
+    return false;
+}
 
 void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const float *q, int nq, const float *inv_norm, const float *lengths,
                       const float *qlen, float mincov, char *ws, int mode, ScanParams *sp) {
     const float *inv = inv_norm;
     if (mode == MS_MODE_COSINE_RAW && inv == nullptr && n > 0) inv = reinterpret_cast<const float *>(ws + pl.off_inv);
     sp->db = db; sp->n = n; sp->nq = nq; sp->nq_pad = pl.nq_pad;
-    sp->qn = queries_used_in_place(q, mode) ? q : reinterpret_cast<const float *>(ws + pl.off_qn);
+    sp->qn = queries_used_in_place(q, mode, pl) ? q : reinterpret_cast<const float *>(ws + pl.off_qn);
+    sp->qnorm_eps = (mode == MS_MODE_IP_NORMQ && queries_used_in_place(q, mode, pl)) ? 1e-12f : 0.0f;
     sp->k = pl.k_pass;
     sp->inv_norm = inv; sp->lengths = lengths; sp->qlen = qlen; sp->mincov = mincov;
     sp->unit_rows = mode == MS_MODE_COSINE_UNIT ? 1 : 0;
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
+    sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -653,10 +609,10 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
 int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q, int nq, int mode,
                  const float *inv_norm, const float *lengths, const float *qlen, float mincov, char *ws,
                  hipStream_t st, ScanParams *sp) {
-    if (!queries_used_in_place(q, mode)) {
+    if (!queries_used_in_place(q, mode, pl)) {
         float *qn = reinterpret_cast<float *>(ws + pl.off_qn);
         hipLaunchKernelGGL(ms_prepare_queries_kernel, dim3((pl.nq_pad + 3) / 4), dim3(256), 0, st, q, nq, pl.nq_pad,
-                           mode != MS_MODE_IP_PRENORM ? 1 : 0, 1e-8f, qn);
+                           mode != MS_MODE_IP_PRENORM ? 1 : 0, mode == MS_MODE_IP_NORMQ ? 1e-12f : 1e-8f, qn);
         MS_LAUNCH_CHECK("ms_prepare_queries_kernel");
     }
     if (mode == MS_MODE_COSINE_RAW && inv_norm == nullptr && n > 0) {
@@ -800,6 +756,15 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
     if (rc) return rc;
     // ceil(k / 64) passes; pass p returns ranks [64p, 64p + kp) using the last entry of pass
     // p-1 as an exclusive upper bound in the total order.
+    // a handful of queries, one pass: the scan launch merges its own lists (ms_scan_body, last workgroup of a query group)
+    const bool fused = k <= 64 && pl.qwb < 4 && nq <= fused_merge_setting() && pl.P <= 256 && (size_t)pl.k_pass * pl.P <= 4224;
+    if (fused) {
+        uint32_t *ticket = reinterpret_cast<uint32_t *>(ws + pl.off_ticket);
+        if (!ticket_ready(ticket)) MS_HIP_CHECK(hipMemsetAsync(ticket, 0, 64 * sizeof(uint32_t), st));
+        sp.fin_s = out_scores; sp.fin_i = out_idx; sp.fin_row_offset = row_offset; sp.fin_stride = k; sp.ticket = ticket;
+        sp.k = pl.k_pass;
+        return launch_scan(pl, sp, st);
+    }
     for (int col0 = 0; col0 < k; col0 += 64) {
         const int kp = (k - col0) < 64 ? (k - col0) : 64;
         sp.k = kp;

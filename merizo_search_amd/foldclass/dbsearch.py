@@ -125,11 +125,12 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
     return {"scores": scores, "indices": idx}
 
 
-def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True):
+def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True, raw_queries: bool = False):
     """Exact max-inner-product kNN over a database delivered block by block (knn_exact_faiss,
     dbsearch.py:213-248): per block IndexFlat.add/search -> `I += i0` -> ResultHeap merge.
 
-    xq: [nq,d] (already normalised); db_blocks: iterable of float32 [b,d] blocks -- host arrays
+    xq: [nq,d], already normalised -- or raw with raw_queries=True: F.normalize(xq) (eps 1e-12, :303-304) is then applied
+    inside every block's search call (bit-identical to normalising first); db_blocks: iterable of float32 [b,d] blocks -- host arrays
     (memmap slices: streamed through engine.device_blocks, the copy of block b+1 overlapping the
     scan of block b) or device tensors (scanned in place; a resident database is ONE such block).
     Rows are numbered from `row_offset`.  Returns (D float32 [nq,k], I int64 [nq,k]), best first,
@@ -149,7 +150,7 @@ def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to
         ni = block.shape[0]
         if ni == 0:
             continue
-        s, i = engine.ip_topk(block, q, k, row_offset=i0)
+        s, i = engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries)
         if best_s is None:
             best_s, best_i = s, i
         else:
@@ -323,17 +324,19 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
 
     query_dicts = _load_queries(queries, inputs_are_ca, _chain_list(pdb_chain, nq))
     emb = sharded.embed_distributed(network, [qd["coords"] for qd in query_dicts])   # ragged launches, data-parallel over ranks
-    emb = engine.normalized(emb, 1e-12)                                     # F.normalize (:303-304): one launch, out of place
 
     # this rank's rows of the matrix: [lo, hi) of DB_SIZE (all of them on one rank)
     rank, world = sharded.rank_world()
     lo, hi = sharded.shard_bounds(int(dbinfo["DB_SIZE"]), world, rank)
     shard = _resident_shard(target_dict, engine, dbmm, lo, hi, nq, int(topk))
     if shard is not None:
-        Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False)          # ONE scan launch
+        # resident shard: F.normalize (:303-304) + knn_exact_faiss (:213-248) as ONE call -- for the few queries of a CLI
+        # search that is one launch (normalisation in the scan's prologue, merge by its last workgroup)
+        Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False, raw_queries=True)
     else:
         logger.info("database shard of %d rows exceeds the resident budget: streaming blocks of %d rows"
                     % (hi - lo, int(search_batchsize)))
+        emb = engine.normalized(emb, 1e-12)                                 # F.normalize once, out of place; then block by block
         Ds, Is = knn_exact(emb, db_iterator(dbmm[lo:hi], int(search_batchsize)), int(topk), engine, row_offset=lo,
                            to_host=False)
     Ds, Is = sharded.exchange_and_merge(Ds, Is, engine)                   # all-gather + merge; no-op on one rank

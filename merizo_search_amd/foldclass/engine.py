@@ -13,7 +13,8 @@ Engine interface (tensors are torch tensors on the engine's device):
     normalized(x, eps)                                      -> new tensor, rows L2-normalised (F.normalize)
     cosine_rows(db)                                         -> the resident form of a RAW `.pt` matrix for cosine_topk
     cosine_topk(rows, q, k, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
-    ip_topk(db, q, k, row_offset)                           -> (scores [nq,k], idx int64 [nq,k])
+    ip_topk(db, q, k, row_offset, normalize_queries)        -> (scores [nq,k], idx int64 [nq,k]); normalize_queries: q raw,
+                                                               F.normalize (eps 1e-12) fused into the call
     topk_merge(scores [S,nq,k], idx [S,nq,k])               -> (scores [nq,k], idx [nq,k])
     merge_gathered(PackedExchange)                          -> (scores [nq,k], idx [nq,k])  multi-rank merge
     upload_rows(matrix, lo, hi)                             -> rows [lo,hi) of a host matrix as ONE device tensor
@@ -107,8 +108,9 @@ class HipEngine:
         return self._ops.ip_topk(rows, q, k, mode=self._ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
                                  row_offset=row_offset, workspace=self._ws)
 
-    def ip_topk(self, db, q, k, row_offset: int = 0):
-        return self._ops.ip_topk(db, q, k, mode=self._ops.MODE_IP_PRENORM, row_offset=row_offset, workspace=self._ws)
+    def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False):
+        mode = self._ops.MODE_IP_NORMQ if normalize_queries else self._ops.MODE_IP_PRENORM
+        return self._ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
 
     def topk_merge(self, scores, idx):
         return self._ops.topk_merge(scores, idx)

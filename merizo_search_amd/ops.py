@@ -10,7 +10,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 from . import _lib
-from ._lib import DIM, MODE_COSINE_RAW, MODE_COSINE_UNIT, MODE_IP_PRENORM, MerizoHipError, check, ptr
+from ._lib import DIM, MODE_COSINE_RAW, MODE_COSINE_UNIT, MODE_IP_NORMQ, MODE_IP_PRENORM, MerizoHipError, check, ptr
 
 
 class _on:

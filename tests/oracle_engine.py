@@ -51,8 +51,9 @@ class OracleEngine:
                                None if qlen is None else qlen.numpy(), mincov, row_offset=row_offset)
         return torch.from_numpy(s), torch.from_numpy(i)
 
-    def ip_topk(self, db, q, k, row_offset=0):
-        s, i = orc.ip_topk(db.numpy(), q.numpy(), k, row_offset=row_offset, order=1)
+    def ip_topk(self, db, q, k, row_offset=0, normalize_queries=False):
+        qn = orc.l2_normalize_rows(q.numpy(), 1e-12) if normalize_queries else q.numpy()
+        s, i = orc.ip_topk(db.numpy(), qn, k, row_offset=row_offset, order=1)
         return torch.from_numpy(s), torch.from_numpy(i)
 
     def topk_merge(self, scores, idx):

@@ -532,3 +532,40 @@ def test_staged_scan_twice_after_one_prepare_is_still_exact(torch_gpu):
         ops.ip_topk_scan(d, dq, k, ws)
         ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
         assert np.array_equal(out_i.cpu().numpy(), i_ref) and np.array_equal(out_s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (5000, 1, 10), (200_000, 3, 10), (1_000_000, 1, 10), (1_000_000, 8, 16), (300_000, 5, 1),
+                                    (40, 2, 10), (777, 8, 10)])
+def test_few_queries_merge_inside_the_scan_launch(n, nq, k, torch_gpu):
+    """Up to 8 queries: the last workgroup of the scan launch merges the per-stream lists itself (no merge launch).  Bit-exact
+    against the oracle, also when called again and again on the same workspace (the arrival counters reset themselves) and
+    for shards shorter than k (padding)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    db, q = _norm_db(n, seed=81 + nq), _norm_db(nq, seed=82 + k)
+    d, dq = _dev(torch, db), _dev(torch, q)
+    ws = ops.TopKWorkspace(d.device)
+    s_ref, i_ref = orc.ip_topk(db, q, k, row_offset=5, order=1)
+    for _ in range(3):
+        s, i = ops.ip_topk(d, dq, k, row_offset=5, workspace=ws)
+        assert np.array_equal(i.cpu().numpy(), i_ref)
+        assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("n,nq,k", [(50_000, 1, 10), (50_000, 5, 10), (400_000, 32, 10), (400_000, 33, 10), (400_000, 64, 20), (400_000, 100, 10),
+                                    (1_000_000, 256, 10), (3000, 70, 100)])
+def test_ip_normq_mode_equals_normalize_then_search(n, nq, k, torch_gpu):
+    """MS_MODE_IP_NORMQ (raw queries, F.normalize fused into the call: inside the scan launch up to 64 queries, in the query
+    preparation kernel above) == ms_l2_normalize_rows_to followed by MS_MODE_IP_PRENORM, bit for bit."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    db = _norm_db(n, seed=91)
+    q_raw, _ = syn.raw_queries(nq, seed=92)
+    q_raw = (q_raw * 3.0).astype(np.float32)
+    q_raw[0] = 0.0 if nq > 1 else q_raw[0]                     # a zero query: x / max(0, 1e-12) = 0
+    d, dq = _dev(torch, db), _dev(torch, q_raw)
+    s1, i1 = ops.ip_topk(d, ops.l2_normalize_rows(dq, 1e-12), k)
+    s2, i2 = ops.ip_topk(d, dq, k, mode=ops.MODE_IP_NORMQ)
+    assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))

@@ -61,15 +61,17 @@ __device__ __forceinline__ float ms_xor32_f(float x, int h) { return __uint_as_f
 // block is staged in `ent` (LDS, k * P entries), then k rounds of "best list head wins and its list advances" -- a wave-level
 // arg-max per round, no block barrier, no pool.  Used by ms_head_merge_kernel (one wave per query) and, for a handful of
 // queries, by the last workgroup of the scan launch itself (ms_scan_body).
-template <int PER>      // lists per lane: P <= 64 * PER
+template <int PER, bool STAGED = false>      // lists per lane: P <= 64 * PER; STAGED: `ent` is filled already
 __device__ __forceinline__ void ms_head_merge_wave(uint2 *ent, const float *part_s, const uint32_t *part_i, int P, int k,
                                                    int64_t row_offset, float *out_s, int64_t *out_i, int out_stride, int out_col0,
                                                    float *ub_s, uint32_t *ub_i, int q, int lane) {
     const float *ps = part_s + (size_t)q * k * P;
     const uint32_t *pi = part_i + (size_t)q * k * P;
+    if (!STAGED) {
 #pragma unroll 8
-    for (int e = lane; e < k * P; e += 64) ent[e] = make_uint2(__float_as_uint(ps[e]), pi[e]);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its own LDS writes are in order; no barrier)
+        for (int e = lane; e < k * P; e += 64) ent[e] = make_uint2(__float_as_uint(ps[e]), pi[e]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its own LDS writes are in order; no barrier)
+    }
     float hs[PER];
     uint32_t hi[PER];
     int dep[PER];
@@ -336,51 +338,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         // padding queries of the last tile never pass the filter: threshold +inf (one compare per score)
         if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }
 
-        // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
-        float qreg[64];
-        if (p.qnorm_eps > 0.0f) {
-            // MS_MODE_IP_NORMQ with 1-2 query tiles: F.normalize of the raw queries (dbsearch.py:303-304) inside the scan launch.
-            // The wave normalises the rows of its tile one by one exactly as ms_normalize_rows_kernel does (float2 per lane, the
-            // same butterfly sum, sqrt, max, divide: the same bits) into its own second tile slot, which no DMA has touched yet,
-            // and reads its B operand back from there.
-            float *qn_lds = reinterpret_cast<float *>(slot0 + 1024);
-            const int rows = (p.nq - qtile * 32) < 32 ? (p.nq - qtile * 32) : 32;
-            for (int row = 0; row < 32; ++row) {
-                float2 v = make_float2(0.0f, 0.0f);
-                if (row < rows) {
-                    v = *(reinterpret_cast<const float2 *>(p.qn + (size_t)(qtile * 32 + row) * MS_DIM) + lane);
-                    const float ss = ms_wave_sum_xor(v.x * v.x + v.y * v.y);
-                    const float nrm = fmaxf(sqrtf(ss), p.qnorm_eps);
-                    v.x = v.x / nrm;
-                    v.y = v.y / nrm;
-                }
-                *(reinterpret_cast<float2 *>(qn_lds + row * MS_DIM) + lane) = v;
-            }
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(qn_lds + r * MS_DIM + 64 * h);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const f32x4 v = src[t];
-                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        } else {
-            // p.qn may be the caller's own [nq,128] array (inner-product mode): rows past nq read as zeros
-            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                f32x4 v = src[t];
-                if (!q_valid) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
-            }
-        }
-        // cosine mode, branch-free: without a lengths array the mask test is +inf >= x * 0
-        float my_qlen = 0.0f;
-        if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
-        const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;
-        const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
-        float ubs = INFINITY;
-        uint32_t ubi = 0;
-        if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
         // LDS-DMA of one tile into slot (t & 1).  Instruction `it` fills float4 slots 64 it .. 64 it + 63,
         // i.e. rows 2 it and 2 it + 1; slot (row, cs) must hold logical float4 column cs ^ (row & 15).
         // Per-lane byte offset inside the tile for instruction it:
@@ -422,6 +379,66 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             }
         };
 
+        // tile 0 is requested before the queries are read (and, in MS_MODE_IP_NORMQ, normalised): the first row fetch and the
+        // query preparation overlap
+        const bool any_full_tile = ((row_end - row_begin) >> 5) > 0;
+        if (any_full_tile) issue_dma(0);
+        // B operand: lane (q = r, h) holds Q[q][64 h + s], s = 0..63, for the whole kernel
+        float qreg[64];
+        if (p.qnorm_eps > 0.0f) {
+            // MS_MODE_IP_NORMQ with 1-2 query tiles: F.normalize of the raw queries (dbsearch.py:303-304) inside the scan launch.
+            // The wave normalises the rows of its tile one by one exactly as ms_normalize_rows_kernel does (float2 per lane, the
+            // same butterfly sum, sqrt, max, divide: the same bits) into its own second tile slot, which no DMA has touched yet,
+            // and reads its B operand back from there.
+            float *qn_lds = reinterpret_cast<float *>(slot0 + 1024);
+            const int rows = (p.nq - qtile * 32) < 32 ? (p.nq - qtile * 32) : 32;
+            for (int row0 = 0; row0 < 32; row0 += 16) {          // 16 rows' loads in flight (a row at a time is a chain of L2 round trips)
+                float2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    v[u] = make_float2(0.0f, 0.0f);
+                    if (row0 + u < rows) v[u] = *(reinterpret_cast<const float2 *>(p.qn + (size_t)(qtile * 32 + row0 + u) * MS_DIM) + lane);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (row0 + u < rows) {
+                        const float ss = ms_wave_sum_xor(v[u].x * v[u].x + v[u].y * v[u].y);
+                        const float nrm = fmaxf(sqrtf(ss), p.qnorm_eps);
+                        v[u].x = v[u].x / nrm;
+                        v[u].y = v[u].y / nrm;
+                    }
+                    *(reinterpret_cast<float2 *>(qn_lds + (row0 + u) * MS_DIM) + lane) = v[u];
+                }
+                if (row0 + 16 >= rows) {                          // the remaining rows are padding: zeros
+                    for (int row = row0 + 16; row < 32; ++row) *(reinterpret_cast<float2 *>(qn_lds + row * MS_DIM) + lane) = make_float2(0.0f, 0.0f);
+                    break;
+                }
+            }
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(qn_lds + r * MS_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const f32x4 v = src[t];
+                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else {
+            // p.qn may be the caller's own [nq,128] array (inner-product mode): rows past nq read as zeros
+            const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                f32x4 v = src[t];
+                if (!q_valid) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
+            }
+        }
+        // cosine mode, branch-free: without a lengths array the mask test is +inf >= x * 0
+        float my_qlen = 0.0f;
+        if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
+        const float qlen_eff = (AUX && p.lengths == nullptr) ? INFINITY : my_qlen;
+        const float mincov_eff = (AUX && p.lengths == nullptr) ? 0.0f : p.mincov;
+        float ubs = INFINITY;
+        uint32_t ubi = 0;
+        if (UB) { ubs = p.ub_s[qidx]; ubi = p.ub_i[qidx]; }
         // Scores of registers 4g..4g+3 of a finished tile -> sc (cosine mode: * 1/|row|, * length
         // mask) and pass masks.  Branch-free so that it can sit between the MFMAs of the next
         // tile; CHECK_ROWS (row < row_end) is only needed for the last tile of a stream, which is
@@ -559,8 +576,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
-            issue_dma(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (tile 0 was requested in front of the query load)
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -704,12 +720,41 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const bool i_am_last = *last_flag != 0u;
         __syncthreads();
         if (i_am_last) {
-            uint2 *ent = reinterpret_cast<uint2 *>(smem + (size_t)wave * 33792);            // 33 KiB per wave: k * P <= 4224 entries
-            for (int lq = wave; lq < p.qwb * 32; lq += 4) {
-                const int qq = qg * p.qwb * 32 + lq;
-                if (qq >= p.nq) break;
-                ms_head_merge_wave<4>(ent, p.part_s, p.part_i, p.P, p.k, p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0, nullptr,
-                                      nullptr, qq, lane);
+            // four queries at a time: all 256 threads stage their [k][P] blocks (33 KiB of LDS per query: k * P <= 4224 entries),
+            // then one wave per query runs the k head-advance rounds
+            const int q_first = qg * p.qwb * 32;
+            const int q_count = (p.nq - q_first) < p.qwb * 32 ? (p.nq - q_first) : p.qwb * 32;
+            const int kP = p.k * p.P;
+            for (int q0 = 0; q0 < q_count; q0 += 4) {
+                const int nq4 = (q_count - q0) < 4 ? (q_count - q0) : 4;
+                // (the blocks of consecutive queries are contiguous in part_s / part_i: a straight copy, 16 bytes per lane and load
+                //  when k * P is a multiple of 4, several loads in flight per thread)
+                const size_t base = (size_t)(q_first + q0) * kP;
+                if ((kP & 3) == 0) {
+                    const f32x4 *ps4 = reinterpret_cast<const f32x4 *>(p.part_s + base);
+                    const uint4 *pi4 = reinterpret_cast<const uint4 *>(p.part_i + base);
+                    const int n4 = nq4 * (kP >> 2), kP4 = kP >> 2;
+#pragma unroll 4
+                    for (int e = tid; e < n4; e += 256) {
+                        const f32x4 sv = ps4[e];
+                        const uint4 iv = pi4[e];
+                        const int w = (e >= 3 * kP4) ? 3 : ((e >= 2 * kP4) ? 2 : ((e >= kP4) ? 1 : 0));
+                        uint2 *dst = reinterpret_cast<uint2 *>(smem + (size_t)w * 33792) + 4 * (e - w * kP4);
+                        dst[0] = make_uint2(__float_as_uint(sv.x), iv.x); dst[1] = make_uint2(__float_as_uint(sv.y), iv.y);
+                        dst[2] = make_uint2(__float_as_uint(sv.z), iv.z); dst[3] = make_uint2(__float_as_uint(sv.w), iv.w);
+                    }
+                } else {
+#pragma unroll 4
+                    for (int e = tid; e < nq4 * kP; e += 256) {
+                        const int w = (e >= 3 * kP) ? 3 : ((e >= 2 * kP) ? 2 : ((e >= kP) ? 1 : 0));
+                        reinterpret_cast<uint2 *>(smem + (size_t)w * 33792)[e - w * kP] = make_uint2(__float_as_uint(p.part_s[base + e]), p.part_i[base + e]);
+                    }
+                }
+                __syncthreads();
+                if (wave < nq4)
+                    ms_head_merge_wave<4, true>(reinterpret_cast<uint2 *>(smem + (size_t)wave * 33792), p.part_s, p.part_i, p.P, p.k,
+                                                p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0, nullptr, nullptr, q_first + q0 + wave, lane);
+                __syncthreads();
             }
             if (tid == 0) p.ticket[qg] = 0u;             // (visible to the next launch: kernel boundary)
         }
@@ -1277,7 +1322,7 @@ __global__ __launch_bounds__(256, 1) void ms_scan_sample_kernel(const ScanParams
 
 // ------------------------------------------------------------------ launch plan + launch templates
 struct ScanPlan {
-    int n_qtiles, qwb, n_qgroups, nq_pad;
+    int n_qtiles, qwb, n_qgroups, nq_pad, nq_real;
     int k_pass;            // ranks per pass (<= 64)
     int kl;                // list entries per lane: smallest of {5,10,32} with 2*kl >= k_pass
     int rows_per_stream, n_streams, n_sgroups, P;

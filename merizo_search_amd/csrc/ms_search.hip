@@ -378,9 +378,14 @@ bool ticket_ready(const void *ticket_area) {
     g_ticket_ready_next = (g_ticket_ready_next + 1) % 32;
     return false;
 }
+int inkernel_norm_setting() {      // MS_MODE_IP_NORMQ: up to this many queries are normalised by the scan's own waves (one batch of row loads)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_INKERNEL_NORM_MAX_NQ"); v = e ? atoi(e) : 4; }
+    return v;
+}
 int fused_merge_setting() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("MS_FUSED_MERGE_MAX_NQ"); v = e ? atoi(e) : 8; }      // diagnostics: 0 = always a merge launch
+    if (v < 0) { const char *e = getenv("MS_FUSED_MERGE_MAX_NQ"); v = e ? atoi(e) : 2; }      // diagnostics: 0 = always a merge launch
     return v;
 }
 
@@ -411,6 +416,7 @@ int pick_kl(int k_pass) {
 ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     ScanPlan pl;
     pl.n_qtiles = (nq + 31) / 32;
+    pl.nq_real = nq;
     pl.qwb = pl.n_qtiles >= 3 ? 4 : (pl.n_qtiles == 2 ? 2 : 1);
     pl.n_qgroups = (pl.n_qtiles + pl.qwb - 1) / pl.qwb;
     pl.nq_pad = pl.n_qgroups * pl.qwb * 32;
@@ -541,7 +547,7 @@ extern "C" int ms_debug_stamps(unsigned long long *host, int words) {
 // own query tile (ScanParams::qnorm_eps); larger batches get the prepared copy (ms_prepare_queries_kernel, eps 1e-12).
 bool queries_used_in_place(const float *q, int mode, const ScanPlan &pl) {
     if (mode == MS_MODE_IP_PRENORM) return ((uintptr_t)q & 15) == 0;
-    if (mode == MS_MODE_IP_NORMQ) return pl.qwb < 4 && ((uintptr_t)q & 7) == 0;
+    if (mode == MS_MODE_IP_NORMQ) return pl.qwb < 4 && pl.nq_real <= inkernel_norm_setting() && ((uintptr_t)q & 7) == 0;
     return false;
 }
 

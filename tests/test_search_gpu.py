@@ -537,7 +537,8 @@ def test_staged_scan_twice_after_one_prepare_is_still_exact(torch_gpu):
 @pytest.mark.parametrize("n,nq,k", [(1, 1, 1), (5000, 1, 10), (200_000, 3, 10), (1_000_000, 1, 10), (1_000_000, 8, 16), (300_000, 5, 1),
                                     (40, 2, 10), (777, 8, 10)])
 def test_few_queries_merge_inside_the_scan_launch(n, nq, k, torch_gpu):
-    """Up to 8 queries: the last workgroup of the scan launch merges the per-stream lists itself (no merge launch).  Bit-exact
+    """Few queries (<= MS_FUSED_MERGE_MAX_NQ: 2 by default, 8 under tests/conftest.py): the last workgroup of the scan launch
+    merges the per-stream lists itself (no merge launch).  Bit-exact
     against the oracle, also when called again and again on the same workspace (the arrival counters reset themselves) and
     for shards shorter than k (padding)."""
     torch = torch_gpu
@@ -553,11 +554,11 @@ def test_few_queries_merge_inside_the_scan_launch(n, nq, k, torch_gpu):
         assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
 
 
-@pytest.mark.parametrize("n,nq,k", [(50_000, 1, 10), (50_000, 5, 10), (400_000, 32, 10), (400_000, 33, 10), (400_000, 64, 20), (400_000, 100, 10),
+@pytest.mark.parametrize("n,nq,k", [(50_000, 1, 10), (50_000, 5, 10), (50_000, 16, 10), (50_000, 17, 10), (400_000, 32, 10), (400_000, 33, 10), (400_000, 64, 20), (400_000, 100, 10),
                                     (1_000_000, 256, 10), (3000, 70, 100)])
 def test_ip_normq_mode_equals_normalize_then_search(n, nq, k, torch_gpu):
-    """MS_MODE_IP_NORMQ (raw queries, F.normalize fused into the call: inside the scan launch up to 64 queries, in the query
-    preparation kernel above) == ms_l2_normalize_rows_to followed by MS_MODE_IP_PRENORM, bit for bit."""
+    """MS_MODE_IP_NORMQ (raw queries, F.normalize fused into the call: inside the scan launch for a handful of queries
+    (MS_INKERNEL_NORM_MAX_NQ), in the query preparation kernel above) == ms_l2_normalize_rows_to followed by MS_MODE_IP_PRENORM, bit for bit."""
     torch = torch_gpu
     from merizo_search_amd import ops
     from merizo_search_amd.foldclass import synthetic as syn

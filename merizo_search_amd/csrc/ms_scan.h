@@ -35,7 +35,7 @@ struct ScanParams {
     int64_t *fin_i;
     int64_t fin_row_offset;
     int fin_stride;
-    uint32_t *ticket;       // [n_qgroups] arrival counters, zero between launches (the last arriver resets its counter)
+    uint32_t *ticket;       // [n_qgroups] arrival counters in library-owned memory, zero between launches (the last arriver resets its counter)
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
     int rows_per_stream;    // multiple of 32
@@ -49,6 +49,18 @@ struct ScanParams {
     unsigned long long *stamps;   // diagnostic builds only: per compute wave {cycles, 100 MHz ticks, tiles, 0}
 #endif
 };
+
+#ifdef MS_STAMP
+// diagnostic builds: phase stamps of ms_scan_body (100 MHz ticks, absolute), 8 words per (workgroup, wave); the sample pass
+// writes into the second half of the buffer
+#define MS_BODY_STAMP(slot)                                                                                             \
+    do {                                                                                                               \
+        if (lane == 0 && p.stamps != nullptr && bid < 4096)                                                            \
+            (p.stamps + (MAXONLY ? 8 * 8 * 4096 : 0) + ((size_t)bid * 8 + wave) * 8)[slot] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define MS_BODY_STAMP(slot) do { } while (0)
+#endif
 
 // value of `x` in the partner lane (lane ^ 32): one v_permlane32_swap + one select, no LDS
 __device__ __forceinline__ uint32_t ms_xor32_u(uint32_t x, int h) {
@@ -295,6 +307,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 
     // block id -> (stream group, query group); groups sharing rows get ids 8 apart (same XCD, L2 reuse)
     const int bid = blockIdx.x;
+    MS_BODY_STAMP(0);
     const int per_super = 8 * p.n_qgroups;
     const int super = bid / per_super, within = bid % per_super;
     const int sgroup = super * 8 + (within & 7);
@@ -305,7 +318,6 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     const int stream = sgroup * spb + sw;
     const int qtile = qg * p.qwb + qw;
     const bool active = stream < p.n_streams && qtile < p.n_qtiles;
-
     ScanState<KL> st;
 #pragma unroll
     for (int j = 0; j < KL; ++j) { st.ls[j] = -INFINITY; st.li[j] = MS_IDX_NONE; }
@@ -431,6 +443,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
                 qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
             }
         }
+        MS_BODY_STAMP(1);
         // cosine mode, branch-free: without a lengths array the mask test is +inf >= x * 0
         float my_qlen = 0.0f;
         if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
@@ -577,6 +590,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (tile 0 was requested in front of the query load)
+            MS_BODY_STAMP(2);
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) areg[tt] = slot0[r * 32 + ((16 * h + tt) ^ (r & 15))];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -630,6 +644,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
             if (any != 0) ms_tile_insert<KL>(st, sc, m, tail_row0, r, h);
         }
     }
+    MS_BODY_STAMP(3);
     if (MAXONLY && active) {
         // the stream's list = the two half-tile maxima of the lane pair (distinct rows), best first,
         // in lane q; lane q+32 stays empty
@@ -673,31 +688,75 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         for (int j = 0; j < KL; ++j) mine[j] = make_uint2(__float_as_uint(ls[j]), li[j]);
     }
     __syncthreads();
-    for (int pair = wave; pair < p.qwb * 32; pair += 4) {
-        const int pqw = pair >> 5, pq = pair & 31;
-        uint2 *dst = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;
-        for (int s2 = 1; s2 < spb; ++s2) {
-            const uint2 *src = lists + ((size_t)(pqw * spb + s2) * 32 + pq) * K2;
-            const uint2 e = (lane < K2) ? src[lane] : make_uint2(0u, MS_IDX_NONE);
-            const uint2 last = dst[K2 - 1];
-            const bool cand = lane < K2 && e.y != MS_IDX_NONE &&
-                              ms_better(__uint_as_float(e.x), e.y, __uint_as_float(last.x), last.y);
-            const int c = __popcll(__ballot(cand));   // sorted source: survivors form a prefix
-            for (int i = 0; i < c; ++i)
-                ms_wave_insert(dst, K2, ms_readlane_f(__uint_as_float(e.x), i), ms_readlane_u(e.y, i), lane);
+    // The 4/qwb stream lists of a query (sorted, K2 entries each, empty slots last) -> its best p.k, by rank: every entry is its
+    // own position plus, per other list, a binary search for the entries that beat it (rows are distinct, so are ranks).
+    uint2 *merged = lists + 128 * K2;                  // [qwb * 32 queries][p.k]
+    for (int e = tid; e < p.qwb * 32 * p.k; e += 256) merged[e] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
+    __syncthreads();
+    {
+        // (the searches of a thread's items run in lockstep: C items x spb lists independent LDS reads per step)
+        constexpr int STEP0 = K2 >= 64 ? 64 : (K2 >= 32 ? 32 : (K2 >= 16 ? 16 : (K2 >= 8 ? 8 : (K2 >= 4 ? 4 : 2))));
+        constexpr int PER_THREAD = K2 / 2;             // 128 * K2 items over 256 threads
+        constexpr int C = (PER_THREAD % 5 == 0) ? 5 : ((PER_THREAD % 4 == 0) ? 4 : 1);
+        for (int c0 = 0; c0 < PER_THREAD; c0 += C) {
+            uint2 e[C];
+            const uint2 *grp[C];
+            int mys[C], lo[C][4];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int it = tid + (c0 + c) * 256;
+                const int li_ = it / K2;               // list index: (pqw * spb + s) * 32 + pq
+                e[c] = lists[it];
+                const int pq = li_ & 31, ws_ = li_ >> 5;
+                const int pqw = ws_ / spb;
+                mys[c] = ws_ - pqw * spb;
+                grp[c] = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;      // list s2 of the group: + s2 * 32 * K2
+#pragma unroll
+                for (int u = 0; u < 4; ++u) lo[c][u] = 0;
+            }
+#pragma unroll
+            for (int step = STEP0; step >= 1; step >>= 1) {
+                uint2 o[C][4];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int mid = lo[c][u] + step - 1;
+                        o[c][u] = grp[c][(u < spb ? u : mys[c]) * 32 * K2 + (mid < K2 ? mid : K2 - 1)];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int mid = lo[c][u] + step - 1;
+                        if (mid < K2 && ms_better(__uint_as_float(o[c][u].x), o[c][u].y, __uint_as_float(e[c].x), e[c].y)) lo[c][u] = mid + 1;
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int it = tid + (c0 + c) * 256;
+                const int li_ = it / K2;
+                int rank = 0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank += (u < spb) ? lo[c][u] : 0;
+                if (e[c].y != MS_IDX_NONE && rank < p.k) merged[(li_ / (32 * spb) * 32 + (li_ & 31)) * p.k + rank] = e[c];
+            }
         }
     }
     __syncthreads();
     for (int e = tid; e < p.qwb * 32 * p.k; e += 256) {
-        const int lq = e / p.k, rank = e % p.k;        // lq = qw*32 + q
+        const int lq = e / p.k, rank = e - lq * p.k;   // lq = qw*32 + q
         const int pqw = lq >> 5, pq = lq & 31;
         const int qt = qg * p.qwb + pqw;
         if (qt >= p.n_qtiles) continue;
-        const uint2 v = lists[((size_t)(pqw * spb) * 32 + pq) * K2 + rank];
+        const uint2 v = merged[e];
         const size_t o = ((size_t)(qt * 32 + pq) * p.k + rank) * p.P + sgroup;
         p.part_s[o] = __uint_as_float(v.x);
         p.part_i[o] = v.y;
     }
+    MS_BODY_STAMP(4);
     if (!MAXONLY && p.fin_s != nullptr) {
         // One launch per search for a handful of queries: the last workgroup of this query group to get here merges.
         // Hand-off by the book (cdna_hip_programming.md Guideline 16): every storing wave drains its stores, workgroup
@@ -720,45 +779,49 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
         const bool i_am_last = *last_flag != 0u;
         __syncthreads();
         if (i_am_last) {
-            // four queries at a time: all 256 threads stage their [k][P] blocks (33 KiB of LDS per query: k * P <= 4224 entries),
-            // then one wave per query runs the k head-advance rounds
+            MS_BODY_STAMP(6);
+            // one query at a time: all 256 threads stage its [k][P] block (k * P <= 4224 entries, 33 KiB), then merge it as a
+            // workgroup (ms_block_merge)
             const int q_first = qg * p.qwb * 32;
             const int q_count = (p.nq - q_first) < p.qwb * 32 ? (p.nq - q_first) : p.qwb * 32;
             const int kP = p.k * p.P;
-            for (int q0 = 0; q0 < q_count; q0 += 4) {
-                const int nq4 = (q_count - q0) < 4 ? (q_count - q0) : 4;
-                // (the blocks of consecutive queries are contiguous in part_s / part_i: a straight copy, 16 bytes per lane and load
-                //  when k * P is a multiple of 4, several loads in flight per thread)
+            uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
+            for (int q0 = 0; q0 < q_count; ++q0) {
                 const size_t base = (size_t)(q_first + q0) * kP;
                 if ((kP & 3) == 0) {
                     const f32x4 *ps4 = reinterpret_cast<const f32x4 *>(p.part_s + base);
                     const uint4 *pi4 = reinterpret_cast<const uint4 *>(p.part_i + base);
-                    const int n4 = nq4 * (kP >> 2), kP4 = kP >> 2;
 #pragma unroll 4
-                    for (int e = tid; e < n4; e += 256) {
+                    for (int e = tid; e < (kP >> 2); e += 256) {
                         const f32x4 sv = ps4[e];
                         const uint4 iv = pi4[e];
-                        const int w = (e >= 3 * kP4) ? 3 : ((e >= 2 * kP4) ? 2 : ((e >= kP4) ? 1 : 0));
-                        uint2 *dst = reinterpret_cast<uint2 *>(smem + (size_t)w * 33792) + 4 * (e - w * kP4);
+                        uint2 *dst = ent + 4 * e;
                         dst[0] = make_uint2(__float_as_uint(sv.x), iv.x); dst[1] = make_uint2(__float_as_uint(sv.y), iv.y);
                         dst[2] = make_uint2(__float_as_uint(sv.z), iv.z); dst[3] = make_uint2(__float_as_uint(sv.w), iv.w);
                     }
                 } else {
 #pragma unroll 4
-                    for (int e = tid; e < nq4 * kP; e += 256) {
-                        const int w = (e >= 3 * kP) ? 3 : ((e >= 2 * kP) ? 2 : ((e >= kP) ? 1 : 0));
-                        reinterpret_cast<uint2 *>(smem + (size_t)w * 33792)[e - w * kP] = make_uint2(__float_as_uint(p.part_s[base + e]), p.part_i[base + e]);
-                    }
+                    for (int e = tid; e < kP; e += 256) ent[e] = make_uint2(__float_as_uint(p.part_s[base + e]), p.part_i[base + e]);
                 }
                 __syncthreads();
-                if (wave < nq4)
-                    ms_head_merge_wave<4, true>(reinterpret_cast<uint2 *>(smem + (size_t)wave * 33792), p.part_s, p.part_i, p.P, p.k,
-                                                p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0, nullptr, nullptr, q_first + q0 + wave, lane);
+                MS_BODY_STAMP(7);
+                const uint2 *fin = ms_block_merge(ent, smem, p.P, p.k, tid);
+                if (fin == nullptr) {        // (uniform across the workgroup) the shapes it declines: head-advance merge by one wave
+                    if (wave == 0)
+                        ms_head_merge_wave<4, true>(ent, p.part_s, p.part_i, p.P, p.k, p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0,
+                                                    nullptr, nullptr, q_first + q0, lane);
+                } else if (tid < p.k) {
+                    const uint2 v = fin[tid];
+                    const size_t o = (size_t)(q_first + q0) * p.fin_stride + tid;
+                    p.fin_s[o] = __uint_as_float(v.x);
+                    p.fin_i[o] = v.y == MS_IDX_NONE ? (int64_t)-1 : p.fin_row_offset + (int64_t)v.y;
+                }
                 __syncthreads();
             }
             if (tid == 0) p.ticket[qg] = 0u;             // (visible to the next launch: kernel boundary)
         }
     }
+    MS_BODY_STAMP(5);
 }
 
 // ------------------------------------------------------------------ scan, loader-wave form
@@ -1330,7 +1393,7 @@ struct ScanPlan {
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
     size_t lds_bytes;
     // workspace carve (byte offsets)
-    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, off_ticket, total;
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, total;
 };
 
 inline int loader_wave_setting() {

@@ -31,6 +31,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 
 thread_local char ms_err_buf[512] = "";
@@ -198,6 +199,48 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
                             ub_s, ub_i, blockIdx.x, threadIdx.x);
 }
 
+// The same merge by a whole workgroup per query (ms_block_merge: threshold = the k-th best list head, then the few entries at
+// or above it rank themselves; no serial rounds).  The form launch_merge uses for P <= 256 lists when the [k][P] block
+// fits in LDS; shapes ms_block_merge declines (fewer lists than k, ties by the hundred) go through the head-advance merge of
+// the workgroup's first wave.
+__global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
+                                                             int64_t row_offset, float *out_s, int64_t *out_i,
+                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int q = blockIdx.x, tid = threadIdx.x, kP = k * P;
+    uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
+    const size_t base = (size_t)q * kP;
+    if ((kP & 3) == 0) {
+        const float4 *ps4 = reinterpret_cast<const float4 *>(part_s + base);
+        const uint4 *pi4 = reinterpret_cast<const uint4 *>(part_i + base);
+#pragma unroll 4
+        for (int e = tid; e < (kP >> 2); e += 256) {
+            const float4 sv = ps4[e];
+            const uint4 iv = pi4[e];
+            uint2 *dst = ent + 4 * e;
+            dst[0] = make_uint2(__float_as_uint(sv.x), iv.x); dst[1] = make_uint2(__float_as_uint(sv.y), iv.y);
+            dst[2] = make_uint2(__float_as_uint(sv.z), iv.z); dst[3] = make_uint2(__float_as_uint(sv.w), iv.w);
+        }
+    } else {
+#pragma unroll 4
+        for (int e = tid; e < kP; e += 256) ent[e] = make_uint2(__float_as_uint(part_s[base + e]), part_i[base + e]);
+    }
+    __syncthreads();
+    const uint2 *fin = ms_block_merge(ent, smem, P, k, tid);
+    if (fin == nullptr) {        // (uniform across the workgroup)
+        if (tid < 64)
+            ms_head_merge_wave<4, true>(ent, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, q, tid);
+        return;
+    }
+    if (tid < k) {
+        const uint2 v = fin[tid];
+        const size_t o = (size_t)q * out_stride + out_col0 + tid;
+        out_s[o] = __uint_as_float(v.x);
+        out_i[o] = v.y == MS_IDX_NONE ? (int64_t)-1 : row_offset + (int64_t)v.y;
+        if (tid == k - 1 && ub_s != nullptr) { ub_s[q] = __uint_as_float(v.x); ub_i[q] = v.y; }
+    }
+}
+
 // ------------------------------------------------------------------ sample bound -------
 // Lower bound of the full pass from the sample pass's lists: the k-th largest (with multiplicity) of the first
 // `ranks` entries of all P lists of a query -- scores of distinct rows, so at least k rows score >= the result.
@@ -338,6 +381,12 @@ int head_merge_setting() {
     return v;
 }
 
+int block_merge_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_BLOCK_MERGE"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = the head-advance merge
+    return v;
+}
+
 int sample_min_queries_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_SAMPLE_MIN_NQ"); v = e ? atoi(e) : 8; }
@@ -366,17 +415,29 @@ void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
     g_hist_clean_next = (g_hist_clean_next + 1) % 16;
 }
 
-// Arrival counters of the in-launch merge: zeroed once per workspace (the last arriver leaves its counter at zero), which this
-// table remembers; a workspace it does not know gets a hipMemsetAsync.
-const void *g_ticket_ready[32];
-int g_ticket_ready_next = 0;
-bool ticket_ready(const void *ticket_area) {
+// The arrival counters of the in-launch merge must be zero when a launch starts, and the launch leaves them that way (the
+// last arriver resets its counter).  They do NOT live in the caller's workspace -- memory the library cannot vouch for
+// between calls (a freed workspace's address may come back holding anything) -- but in a small block the library allocates
+// and zeroes itself, one per (workspace pointer, device): calls that share a workspace are serialised by the caller anyway
+// (they share the partial lists), so they may share the block.  No block left (more than 64 workspaces alive): the search
+// runs with a merge launch instead.
+struct SyncBlock { const void *ws; int dev; char *mem; };
+constexpr int SYNC_BLOCKS = 64;
+constexpr size_t SYNC_BYTES = 256;         // 64 arrival counters of the in-launch merge
+SyncBlock g_sync[SYNC_BLOCKS];
+int g_sync_used = 0;
+char *sync_block_for(const void *ws) {
     std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
-    for (const void *e : g_ticket_ready)
-        if (e == ticket_area) return true;
-    g_ticket_ready[g_ticket_ready_next] = ticket_area;
-    g_ticket_ready_next = (g_ticket_ready_next + 1) % 32;
-    return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    for (int i = 0; i < g_sync_used; ++i)
+        if (g_sync[i].ws == ws && g_sync[i].dev == dev) return g_sync[i].mem;
+    if (g_sync_used == SYNC_BLOCKS) return nullptr;
+    char *mem = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&mem), SYNC_BYTES) != hipSuccess) return nullptr;
+    if (hipMemset(mem, 0, SYNC_BYTES) != hipSuccess) { (void)hipFree(mem); return nullptr; }
+    g_sync[g_sync_used++] = SyncBlock{ws, dev, mem};
+    return mem;
 }
 int inkernel_norm_setting() {      // MS_MODE_IP_NORMQ: up to this many queries are normalised by the scan's own waves (one batch of row loads)
     static int v = -1;
@@ -436,7 +497,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
     pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
     pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
-    pl.lds_bytes = 4 * 32768 + 4 * 1024;
+    pl.lds_bytes = 4 * 32768 + 4 * 1024;        // tile slots, cosine side data, in-launch bound
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     // Size of the sample: T0 tiles per stream cost T0 tile times; the insertion steps they save in the
@@ -464,7 +525,6 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
     pl.off_scr_i = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(int64_t), 256);
     pl.off_hist = off;    off += ms_align_up((size_t)pl.nq_pad * 16 * sizeof(uint32_t), 256);
     pl.off_hstep = off;   off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
-    pl.off_ticket = off;  off += ms_align_up((size_t)(pl.n_qgroups > 64 ? pl.n_qgroups : 64) * sizeof(uint32_t), 256);
     pl.total = off;
     return pl;
 }
@@ -499,6 +559,16 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
+    const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
+    if (block_lds <= 156 * 1024 && pl.P <= 256 && block_merge_setting()) {     // the usual case: a workgroup per query
+        if (block_lds > 48 * 1024)
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
+        hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
+                           out_i, out_stride, col0, ub_s, ub_i);
+        MS_LAUNCH_CHECK("ms_block_merge_kernel");
+        return MS_OK;
+    }
     if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
@@ -763,10 +833,10 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
     // ceil(k / 64) passes; pass p returns ranks [64p, 64p + kp) using the last entry of pass
     // p-1 as an exclusive upper bound in the total order.
     // a handful of queries, one pass: the scan launch merges its own lists (ms_scan_body, last workgroup of a query group)
-    const bool fused = k <= 64 && pl.qwb < 4 && nq <= fused_merge_setting() && pl.P <= 256 && (size_t)pl.k_pass * pl.P <= 4224;
-    if (fused) {
-        uint32_t *ticket = reinterpret_cast<uint32_t *>(ws + pl.off_ticket);
-        if (!ticket_ready(ticket)) MS_HIP_CHECK(hipMemsetAsync(ticket, 0, 64 * sizeof(uint32_t), st));
+    char *blk = (k <= 64 && pl.qwb < 4 && nq <= fused_merge_setting() && pl.P <= 256 && (size_t)pl.k_pass * pl.P <= 4224)
+                    ? sync_block_for(ws) : nullptr;
+    if (blk != nullptr) {
+        uint32_t *ticket = reinterpret_cast<uint32_t *>(blk);
         sp.fin_s = out_scores; sp.fin_i = out_idx; sp.fin_row_offset = row_offset; sp.fin_stride = k; sp.ticket = ticket;
         sp.k = pl.k_pass;
         return launch_scan(pl, sp, st);

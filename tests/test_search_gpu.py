@@ -570,3 +570,28 @@ def test_ip_normq_mode_equals_normalize_then_search(n, nq, k, torch_gpu):
     s1, i1 = ops.ip_topk(d, ops.l2_normalize_rows(dq, 1e-12), k)
     s2, i2 = ops.ip_topk(d, dq, k, mode=ops.MODE_IP_NORMQ)
     assert torch.equal(i1, i2) and torch.equal(s1.view(torch.int32), s2.view(torch.int32))
+
+
+@pytest.mark.parametrize("n,nq,k", [(300_000, 1, 10), (300_000, 40, 10), (1_000_000, 8, 16), (200_000, 300, 10), (300_000, 20, 64),
+                                    (900, 3, 10), (4000, 33, 20)])
+def test_merge_by_threshold_handles_ties_by_the_hundred_and_short_shards(n, nq, k, torch_gpu):
+    """The workgroup merge (threshold = k-th best list head, survivors rank themselves) and the shapes it hands to the
+    head-advance merge: every score equal (hundreds of entries tie with the threshold), blocks of duplicated rows, shards with
+    fewer lists than k, and ordinary data -- all bit-exact against the oracle, lowest row first among ties."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    q = _norm_db(nq, seed=300 + nq)
+    dq = _dev(torch, q)
+    # (a) every row the same: all scores of a query tie
+    db = np.tile(_norm_db(1, seed=301), (n, 1))
+    s, i = ops.ip_topk(_dev(torch, db), dq, k)
+    assert (i.cpu().numpy() == np.arange(min(k, n))[None, :]).all()
+    # (b) ordinary rows with the best row of query 0 copied into every 1000th row: as many ties at the top as there are lists
+    db = _norm_db(n, seed=302)
+    db[::1000] = q[0]
+    s, i = ops.ip_topk(_dev(torch, db), dq, k)
+    s_ref, i_ref = orc.ip_topk(db, q, k, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+    assert i.cpu().numpy()[0].tolist() == list(range(0, 1000 * k, 1000))[:k] or n < 1000 * k

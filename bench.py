@@ -54,7 +54,7 @@ C4_NQ = 4096
 
 
 def scan_kernel_name(nq, k):
-    return "ms_scan_loader_kernel" if (nq > 64 and k <= 32) else "ms_scan_kernel"
+    return "ms_scan_loader_kernel" if (nq > 64 and k <= 64) else "ms_scan_kernel"
 
 
 def small_batch_note(nq):

@@ -260,7 +260,7 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
 template <int KL, bool HIST = false>
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
                                                int64_t sub_row0, int r, int h, const ScanHist *hg = nullptr) {
-    if (KL <= MS_STATIC_INSERT_MAX_KL) {
+    if (KL <= (HIST ? 16 : MS_STATIC_INSERT_MAX_KL)) {
         // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -277,16 +277,24 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
             }
         }
     } else {
-        // long lists: a single copy of the (32-slot) step inside a runtime loop over the rows keeps
-        // the code size and the build time down
-        for (int row = 0; row < 32; ++row) {
+        // long lists: a single copy of the (32-slot) step inside a runtime loop keeps the code size and the build time
+        // down; the loop visits only the rows that have a candidate (the masks are wave-uniform: scalar work)
+        uint32_t rows = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row0 = 8 * (i >> 2) + (i & 3);            // register i: rows row0 (lanes 0-31) and row0 + 4 (lanes 32-63)
+            rows |= ((uint32_t)m[i] != 0u ? 1u : 0u) << row0;
+            rows |= ((uint32_t)(m[i] >> 32) != 0u ? 1u : 0u) << (row0 + 4);
+        }
+        while (rows != 0u) {
+            const int row = __builtin_ctz(rows);
+            rows &= rows - 1u;
             const int reg = (row & 3) + 4 * (row >> 3), hh = (row >> 2) & 1;
             uint64_t mj = m[0];
             float v = sc[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) { mj = (reg == i) ? m[i] : mj; v = (reg == i) ? sc[i] : v; }
             const uint32_t mm = hh ? (uint32_t)(mj >> 32) : (uint32_t)mj;
-            if (mm == 0) continue;
             ms_row_insert<KL, HIST>(st, v, mm, hh, (uint32_t)(sub_row0 + row), r, h, hg);
         }
     }
@@ -848,6 +856,9 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
 //   * filter of tile t-1: 8 v_max3 fold the lane's 16 scores into one maximum, ONE compare per tile;
 //   * slot base of tile t+1: one v_add; loader flag: one ds_read_b32 + v_readfirstlane; consumed counter: ds_add
 //     under an EXEC mask set by scalar moves.  11 vector instructions per tile in inner-product mode.
+#ifndef MS_HIST_PERIOD
+#define MS_HIST_PERIOD 16        // tiles between two looks at the shared bound's counters (a power of two)
+#endif
 #ifndef MS_LDR_R
 #define MS_LDR_R 8
 #endif
@@ -1265,6 +1276,82 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         }
     };
 
+    // 32-entry lists (k <= 64) leave no room for a whole tile of fragments in registers (64 of them): RING_FRAGS keeps FOUR
+    // fragment registers instead -- group g of the chain waits for its fragment (LDS reads return in order: "all but the
+    // two youngest"), and requests the one three groups ahead, the first three of the next tile during the last three groups.
+    // Same synchronisation with the loader as above, except that a tile is reported as consumed when its last fragment
+    // has been requested (group 12 of its own chain) instead of before its chain starts.
+    constexpr bool RING_FRAGS = KL > 16 && !SAMPLE;
+    uint32_t rb0 = lin0, rb1 = lin0;          // lane base of the slot of the current / next tile (the two stages of a pair swap them)
+    auto stage_ring = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        uint32_t &rcur = FIRST ? rb0 : rb1;
+        uint32_t &rnext = FIRST ? rb1 : rb0;
+        const uint32_t slot_off = (uint32_t)((t + 1) % LDR_R) * 16384u;
+        asm volatile("v_add_u32 %0, %1, %2" : "=v"(rnext) : "s"(slot_off), "v"(lin0));
+        float mx;
+#define MS_RWAIT(TT) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(areg[(TT) & 3]), "+v"(flag) :: "memory")
+#define MS_RREAD(TT)                                                                                           \
+        if ((TT) + 3 < 16) { MS_FRAG_READ(areg[((TT) + 3) & 3], rcur, 512 * (((TT) + 3) & 15)); }             \
+        else { MS_FRAG_READ(areg[((TT) + 3) & 3], rnext, 512 * (((TT) + 3) & 15)); }
+#define MS_RGROUP(TT, ZERO_C)                                                                                  \
+        MS_RWAIT(TT);                                                                                          \
+        if (ZERO_C) { MS_MFMA_Z(out, areg[(TT) & 3].x, qreg[4 * (TT) + 0]); } else { MS_MFMA(out, areg[(TT) & 3].x, qreg[4 * (TT) + 0]); } \
+        MS_MFMA(out, areg[(TT) & 3].y, qreg[4 * (TT) + 1]); MS_MFMA(out, areg[(TT) & 3].z, qreg[4 * (TT) + 2]); MS_MFMA(out, areg[(TT) & 3].w, qreg[4 * (TT) + 3]); \
+        MS_RREAD(TT)
+        MS_RGROUP(0, true)
+        MS_RGROUP(1, false)
+        if (SCALE_IN_CHAIN) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); __builtin_amdgcn_sched_barrier(0); }
+        MS_RGROUP(2, false)
+        if (SCALE_IN_CHAIN) { __builtin_amdgcn_sched_barrier(0); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); __builtin_amdgcn_sched_barrier(0); }
+        MS_RGROUP(3, false)
+        asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(mx) : "v"(prev[0]), "v"(prev[1]), "v"(prev[2]));
+        MS_MAX3(mx, prev[3], prev[4]); MS_MAX3(mx, prev[5], prev[6]); MS_MAX3(mx, prev[7], prev[8]);
+        MS_RGROUP(4, false)
+        MS_MAX3(mx, prev[9], prev[10]); MS_MAX3(mx, prev[11], prev[12]); MS_MAX3(mx, prev[13], prev[14]);
+        asm volatile("v_max_f32 %0, %0, %1" : "+v"(mx) : "v"(prev[15]));
+        MS_RGROUP(5, false)
+        MS_RGROUP(6, false)
+        MS_RGROUP(7, false)
+        MS_RGROUP(8, false)
+        MS_RGROUP(9, false)
+        MS_RGROUP(10, false)
+        MS_RGROUP(11, false)
+        MS_RGROUP(12, false)
+        if (!FIRST) {       // the last fragments of tiles t-1 and t have been requested: both slots may be refilled; then the loader's
+                            // counter for the next pair (both behind the fragment reads in the LDS queue)
+            asm volatile("ds_add_u32 %0, %1" ::"v"(cons_addr), "v"(two) : "memory");
+            asm volatile("ds_read_b32 %0, %1" : "=v"(flag) : "v"(landed_addr) : "memory");
+        }
+        MS_RGROUP(13, false)
+        MS_RGROUP(14, false)
+        MS_RGROUP(15, false)
+#undef MS_RGROUP
+#undef MS_RREAD
+#undef MS_RWAIT
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_expect(__ballot(mx > st.tau) != 0 || (AUXM == 2 && neg_tau), 0)) {
+#ifdef MS_STAMP
+            const unsigned long long i0 = __builtin_amdgcn_s_memtime();
+#endif
+            float sc[16];
+            uint64_t m[16];
+            if (AUXM == 2) { scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
+            ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
+            if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
+#ifdef MS_STAMP
+            stamp_ins += __builtin_amdgcn_s_memtime() - i0;
+            stamp_nins += 1;
+#endif
+        }
+    };
+    auto run_stage = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) __attribute__((always_inline)) {
+        if constexpr (RING_FRAGS) stage_ring(first_c, t, prev, out);
+        else stage(first_c, t, prev, out);
+    };
+
 #ifdef MS_STAMP
     const unsigned long long stamp_c0 = __builtin_amdgcn_s_memtime(), stamp_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long stamp_cm = stamp_c0, stamp_rm = stamp_r0;
@@ -1274,8 +1361,12 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
         landed_seen = wait_landed(1);
+        if (RING_FRAGS) {
+            MS_FRAG_READ(areg[0], lin0, 0); MS_FRAG_READ(areg[1], lin0, 512); MS_FRAG_READ(areg[2], lin0, 1024);
+        } else {
 #pragma unroll
-        for (int f = 0; f < 16; ++f) areg[f] = *reinterpret_cast<const f32x4 *>(smem + (lin0 - ring_lds) + 512 * f);
+            for (int f = 0; f < 16; ++f) areg[f] = *reinterpret_cast<const f32x4 *>(smem + (lin0 - ring_lds) + 512 * f);
+        }
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
@@ -1288,18 +1379,18 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             // shared bound (ScanHist): every 16th tile this query's 16 bucket counters are fetched (sc1: past this CU's L1)
             // while two tiles are multiplied, then the threshold is raised.  The two tests are evaluated separately on purpose
             // (kept apart by the empty asm): carried from one to the other, hipcc keeps the flag in a vector register.
-            if (hist_on && (t & 15) == 8) {
+            if (hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
                              "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
                              : "=&v"(hc0), "=&v"(hc1), "=&v"(hc2), "=&v"(hc3) : "v"(hp) : "memory");
             }
             ensure_landed(t);
-            stage(std::true_type{}, t, acc0, acc1);
-            stage(std::false_type{}, t + 1, acc1, acc0);
+            run_stage(std::true_type{}, t, acc0, acc1);
+            run_stage(std::false_type{}, t + 1, acc1, acc0);
             int t2 = t;
             asm volatile("" : "+s"(t2));
-            if (hist_on && (t2 & 15) == 8) {
+            if (hist_on && (t2 & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
                 const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
@@ -1317,7 +1408,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         }
         if (t < ntl) {
             ensure_landed(t);
-            stage(std::true_type{}, t, acc0, acc1);
+            run_stage(std::true_type{}, t, acc0, acc1);
             acc0 = acc1;
         }
         // the last chain's result is read by compiler-scheduled code next: wait out the matrix pipe (the hazard
@@ -1411,8 +1502,9 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
         MS_LAUNCH_CHECK("ms_scan_sample_kernel");
         return MS_OK;
     }
-    if constexpr (KL <= 16 && !UB) {    // loader-wave form: its compute waves must fit 256 registers WITHOUT spills (the pinned stage
-                                        // cannot tolerate a spill of a register an LDS read is still filling): 32-entry lists do not
+    if constexpr (!UB) {                // loader-wave form: its compute waves must fit 256 registers WITHOUT spills (the pinned stage
+                                        // cannot tolerate a spill of a register an LDS read is still filling): 32-entry lists get there
+                                        // with four fragment registers instead of a tile's sixteen (RING_FRAGS)
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
 #define MS_LAUNCH_LOADER(AUXM)                                                                                           \
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUXM, false>),     \

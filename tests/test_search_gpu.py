@@ -258,6 +258,7 @@ def test_sample_prepass_is_exact_on_adversarial_order(torch_gpu):
 @pytest.mark.parametrize("n,nq,k", [
     (131_073, 96, 10), (131_105, 96, 10), (200_000, 130, 5), (262_113, 97, 1), (400_000, 256, 10), (300_000, 100, 64),
     (1_000_003, 256, 10), (400_000, 130, 21), (400_000, 256, 32), (131_105, 97, 25),
+    (1_000_003, 256, 64), (400_000, 130, 33), (131_105, 97, 50), (20_000, 129, 33), (262_113, 512, 64),
 ])
 def test_loader_wave_scan_with_sample_bound(n, nq, k, torch_gpu):
     """Batches of >= 3 query tiles run the loader-wave kernel, thresholded from its first tile by

@@ -24,6 +24,9 @@ One JSON line is printed by rank 0 (contract in the task statement), with
                 launch against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic
                 bytes (512 B per row) against the 8 TB/s HBM peak; both fractions always included,
                 plus `step_frac`: the same work over the whole step time (what the user gets);
+                `traffic` (HBM bytes per launch) is NOT measured by this run -- counters need the profiler --
+                but copied from the PMC passes of the same workload committed under profiles/ (r03_c2_pmc.json,
+                r03_c4_pmc.json, r03_c3_pmc.json): `traffic_from_committed_profile` / `traffic_source` say so;
   cpu_baseline  the CPU oracle (oracle/oracle.c: AVX2 + OpenMP port of the faiss path) on this host's
                 cores, and under `torch_cpu` the reference's own torch op shapes (oracle/torch_baseline.py)
                 -- per-query cosine_similarity*mask->topk, blockwise-262,144 normalize->Q@D^T->topk->merge,
@@ -31,7 +34,8 @@ One JSON line is printed by rank 0 (contract in the task statement), with
   hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M, 4M and 45.6M rows: GB/s against the HBM peak;
   c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
   k_sweep       (N = 1) the C2 shape at k = 1 / 10 / 20 / 32 / 64;
-  c3_search     (N = 1) C3's search half: 500k RAW rows, 1000 queries, cosine + length mask;
+  c3_search     (N = 1) C3's search half: 500k rows of a `.pt` database (normalised once at load, as the product does),
+                1000 queries, cosine + length mask;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
                 peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
 `--no-extras` skips the last three, `--no-cpu-baseline` the CPU legs.
@@ -80,6 +84,22 @@ def roofline(nq, rows, k, scan_ms, step_ms):
     roof.update({"traffic": None, "kernel": scan_kernel_name(nq, k), "kernel_ms": scan_ms, "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
                  "rows_per_launch": rows, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
     return roof
+
+
+def attach_committed_traffic(roof, pmc_name):
+    """HBM traffic of one launch of the entry's kernel, from the PMC passes of the same workload committed under profiles/
+    (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction: tools/pmc_to_json.py).  NOT measured in
+    this run: counters need the profiler; the fields say so."""
+    path = os.path.join(REPO, "profiles", pmc_name)
+    if not os.path.exists(path):
+        return
+    with open(path) as fh:
+        pmc = json.load(fh)
+    roof["traffic"] = pmc.get("traffic_bytes_per_launch")
+    roof["traffic_from_committed_profile"] = True
+    roof["traffic_source"] = "profiles/%s: %s (committed rocprofv3 --pmc passes, not measured in this run)" % (pmc_name, pmc.get("workload", ""))
+    if pmc.get("matrix_pipe_busy_fraction") is not None:
+        roof["matrix_pipe_busy_fraction_from_committed_profile"] = pmc["matrix_pipe_busy_fraction"]
 
 
 class SearchBench:
@@ -265,6 +285,8 @@ def c3_search_bench(torch, ops, syn, dev, k, log):
            "ms_per_step": ms, "queries_per_s": nq / ms * 1e3, "max_abs_score_error_vs_float64": err,
            "roofline": roofline(nq, n, k, scan_ms, ms)}
     out["roofline"]["kernel"] = "ms_scan_loader_kernel<5, 2> (unit-row cosine variant: in-chain filter on the final scores, length mask in the rare path)"
+    out["roofline"]["algorithmic_bytes_per_launch"] = 516.0 * n          # rows + their lengths
+    attach_committed_traffic(out["roofline"], "r03_c3_pmc.json")
     log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
     del db, unit, lengths, ws
     return out
@@ -436,13 +458,8 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
         roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
-        # HBM traffic of one launch of that kernel: PMC passes of this same command committed under profiles/
-        # (separate --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 2x read correction); not measured live
-        pmc = os.path.join(REPO, "profiles", "r02_c2_pmc.json")
-        if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10) and os.path.exists(pmc):
-            with open(pmc) as fh:
-                roof["traffic"] = json.load(fh)["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r02_c2_pmc.json (committed rocprofv3 --pmc passes of this command, not measured in this run)"
+        if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10):
+            attach_committed_traffic(roof, "r03_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
         elif weak:
@@ -484,6 +501,8 @@ def main():
                                 "ms_per_step": ms4, "queries_per_s": C4_NQ / ms4 * 1e3, "planted_recall": planted4,
                                 "note": "queries_per_s here = the N-GPU rate on an N x 45.6M-row database, minus the all-gather + merge of 480 KB per rank",
                                 "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
+            if k == 10:
+                attach_committed_traffic(line["c4_shard"]["roofline"], "r03_c4_pmc.json")
             log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s, scan %.1f%% of fp32 MFMA peak" % (ms4, C4_NQ / ms4 * 1e3, line["c4_shard"]["roofline"]["frac"] * 100))
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
             small = []

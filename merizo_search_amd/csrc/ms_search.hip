@@ -8,13 +8,13 @@
 // This file: normalisation kernels, the launch plan (row streams x query tiles, workspace carve), the two merges of
 // per-stream lists and the C entry points.  The scan kernels themselves live in ms_scan.h (instantiated per list
 // length in ms_scan_kl*.hip):
-//   ms_scan_loader_kernel<KL,AUX>    >= 3 query tiles (MFMA-bound): 4 compute waves share the rows a fifth wave streams
-//                                    into an LDS ring by LDS-DMA
-//   ms_scan_kernel<KL,AUX,UB>        1-2 query tiles (HBM-bound), k > 20, and passes with an upper bound (k > 64)
-//   ms_scan_sample_kernel<KL,AUX>    sample pass: best rows of the first tiles of every stream -> lower bound per query
+//   ms_scan_loader_kernel<KL,AUXM,SAMPLE>  >= 3 query tiles (MFMA-bound), k <= 64, all modes: 4 compute waves share the rows
+//                                          a fifth wave streams into an LDS ring by LDS-DMA; SAMPLE = its sample pass
+//   ms_scan_kernel<KL,AUX,UB>              1-2 query tiles (HBM-bound), and passes with an upper bound (k > 64)
+//   ms_scan_sample_kernel<KL,AUX>          sample pass of the latter: best scores of the first tiles of every stream
 // Common to all of them: one wave = one (32-query tile, row stream) pair; the query tile is the MFMA B
-// operand in 64 VGPRs for the whole kernel; 32-row tiles arrive by LDS-DMA with an XOR-swizzled source so that the
-// lane = row ds_read_b128 A-fragment reads are conflict free; k-step s of the v_mfma_f32_32x32x2_f32 chain multiplies
+// operand in 64 VGPRs for the whole kernel; 32-row tiles arrive by LDS-DMA in an image whose lane = row ds_read_b128
+// A-fragment reads are conflict free; k-step s of the v_mfma_f32_32x32x2_f32 chain multiplies
 // elements k = s (lanes 0-31) and k = 64 + s (lanes 32-63), i.e. the accumulation order is s = 0..63: (k = s, k = 64 + s)
 // -- restated by oracle/oracle.c:dot_ordered(order = 1), which reproduces the scores bit for bit; the running top-k of a
 // query lives in the registers of its two lanes; rows are visited in ascending order, so "strictly greater than the k-th
@@ -22,7 +22,11 @@
 //
 // Kernels here
 //   ms_normalize_rows_kernel / ms_row_inv_norms_kernel / ms_prepare_queries_kernel   one wave per 512-byte row
-//   ms_head_merge_kernel      per query: k rounds of "best list head wins" over the per-stream lists staged in LDS
+//   ms_block_merge_kernel     per query, one workgroup: threshold = k-th best list head, the few entries at or above it rank
+//                             themselves (ms_common.h: ms_block_merge); the usual final merge
+//   ms_sample_bound_kernel    per query: k-th largest of the sample pass's maxima = lower bound of the full pass
+//   ms_head_merge_kernel      per query: k rounds of "best list head wins" over the per-stream lists staged in LDS (shapes the
+//                             block merge declines, and more than 256 lists)
 //   ms_partial_merge_kernel   the same merge for large k * P (does not fit LDS): threshold from the list heads + pool
 //   ms_kway_merge_kernel      public merge of S sorted lists (shards after the all-gather, blocks when streaming);
 //                             ms_kway_merge_any_kernel beyond 64 lists

@@ -102,6 +102,34 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
 int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_scores, int64_t *out_idx,
                       void *workspace, size_t workspace_bytes, ms_stream_t stream);
 
+/* The same search as ms_ip_topk in the inner-product modes (MS_MODE_IP_PRENORM / MS_MODE_IP_NORMQ) -- index.search of
+ * dbsearch.py:234-242 -- with the SAME results bit for bit, several times faster for batches of more than 64 queries and
+ * k <= 32.  The rows are scanned once with bf16 matrix instructions on operands split in registers (hi + lo halves of every
+ * float: no second copy of the database, no other layout), which gives every score to within 2.5e-4 |row| |q|; the 2k-4k
+ * best rows per query by that score are re-scored with the exact fp32 chain and the best k of them are returned -- after a
+ * per-query proof that no other row can belong to the answer (the k-th exact score exceeds the last kept approximate score
+ * by more than the error bound).  Where the proof fails (dozens of rows within the error bound of the k-th best), the
+ * exact fp32 pipeline, queued behind on the same stream, runs for the batch: always exact, never an approximation.
+ *   row_norm_bound   an upper bound on the L2 norm of every row of db (1.0 for a database of unit vectors, as
+ *                    dbfname_IP holds; 1 / min(ms_row_inv_norms) otherwise); <= 0 or shapes outside the above: the call is
+ *                    ms_ip_topk.
+ * Workspace: ms_ip_topk_prefiltered_workspace_bytes.  _prepare / _scan / _finish: its three stages as for ms_ip_topk
+ * (queries + sample pass; the one scan launch; merge + exact re-scoring + the gated exact pipeline). */
+size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k);
+int ms_ip_topk_prefiltered(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+                           float row_norm_bound, float *out_scores, int64_t *out_idx, void *workspace,
+                           size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound,
+                                   void *workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound,
+                                void *workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_finish(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+                                  float row_norm_bound, float *out_scores, int64_t *out_idx, void *workspace,
+                                  size_t workspace_bytes, ms_stream_t stream);
+/* Diagnostics (tests): synchronises the device; *gate_value == *last_epoch means the last prefiltered search on this
+ * workspace needed the exact pipeline. */
+int ms_debug_prefilter_gate(void *workspace, unsigned int *gate_value, unsigned int *last_epoch);
+
 /* Merge S sorted result lists per query into the best k: faiss.ResultHeap(nq,k).add_result /
  * finalize (dbsearch.py:224,240,245) and the cross-shard merge after the RCCL all-gather.
  * scores float32 [S,nq,k], idx int64 [S,nq,k] (idx < 0 = padding), each list sorted best-first

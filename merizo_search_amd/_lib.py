@@ -47,6 +47,12 @@ SIGNATURES = {
     "ms_ip_topk_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_workspace_bytes": (_sz, [_i64, _int, _int]),
+    "ms_ip_topk_prefiltered": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_finish": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_debug_prefilter_gate": (_int, [_vp, _vp, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge_strided": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_egnn_weight_floats": (_sz, []),

@@ -35,6 +35,10 @@ struct ScanParams {
     int64_t *fin_i;
     int64_t fin_row_offset;
     int fin_stride;
+    int prefilter = 0;      // loader-wave form only: score with three bf16 matrix instructions on the split operands (approximate scores;
+                            // the caller re-scores the survivors exactly: ms_ip_topk_prefiltered)
+    const uint32_t *gate = nullptr;   // NULL, or: the launch does nothing unless *gate == gate_epoch (the exact pipeline behind a
+    uint32_t gate_epoch = 0;          // prefiltered search runs only when the prefilter could not prove its answer)
     uint32_t *ticket;       // [n_qgroups] arrival counters in library-owned memory, zero between launches (the last arriver resets its counter)
     float *part_s;          // [nq_pad][k][P]  rank-major per query, P partial lists
     uint32_t *part_i;
@@ -303,6 +307,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
 template <int KL, bool AUX, bool UB, bool MAXONLY>
 __device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
     // below becomes 64-bit per-lane arithmetic
@@ -912,6 +917,28 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
 #define MS_MAX3(M, A, B) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(M) : "v"(A), "v"(B))
 #define MS_FRAG_READ(DST, BASE, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(BASE), "i"(IMM) : "memory")
 
+// Prefilter (PF): a float x is split into hi = its upper 16 bits (a bf16 by truncation) and lo = the upper 16 bits of
+// x - hi (exact in fp32); x = hi + lo + r with |x - hi| < 2^-7 |x| and |r| < 2^-14 |x|.  Eight consecutive floats of a row
+// (two fragments) become the two 8 x bf16 operands of v_mfma_f32_32x32x16_bf16; the same split of the query is the B side.
+// hi.hi + hi.lo + lo.hi misses lo.lo and the r terms: |approx - exact| <= 3 * 2^-14 |x||q| plus the fp32 accumulation of 384
+// products: < 2.5e-4 |x||q| (MS_PF_ERR).  bf16 x bf16 products are exact in fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MS_PF_ERR 2.5e-4f
+__device__ __forceinline__ void ms_split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &lo) {
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    u32x4_ H, L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t a = __float_as_uint(x[2 * i]), b = __float_as_uint(x[2 * i + 1]);
+        H[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);            // upper halves of b : a
+        const float la = x[2 * i] - __uint_as_float(a & 0xFFFF0000u), lb = x[2 * i + 1] - __uint_as_float(b & 0xFFFF0000u);
+        L[i] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+    }
+    hi = __builtin_bit_cast(bf16x8, H);
+    lo = __builtin_bit_cast(bf16x8, L);
+}
+
 // SAMPLE: the sample pass in this form -- no lists, every lane keeps the maximum of its half of the rows of the first
 // max_tiles FULL tiles of its stream; the two maxima of a lane pair (distinct rows) are the stream's entry for the
 // bound selection (ms_sample_bound_kernel looks at values only).
@@ -920,8 +947,11 @@ __device__ __forceinline__ void ms_vmcnt_tiles() {   // wait until at most N til
 // as they leave the matrix pipe, and a masked row's score (+-0) can only matter to a query whose threshold is negative,
 // so the in-chain filter is the inner-product one and the mask is applied in the rare path (all of a tile's scores are
 // re-derived there); a wave with a negative threshold somewhere visits the rare path for every tile until it is gone.
-template <int KL, int AUXM, bool SAMPLE>
+// PF: the prefilter's scan (inner-product modes): same loader, ring, lists, bounds and merges, on approximate scores.
+template <int KL, int AUXM, bool SAMPLE, bool PF = false>
 __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
+    static_assert(!PF || AUXM == 0, "the prefilter exists for the inner-product modes");
+    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
     constexpr bool AUX = AUXM != 0;
     constexpr bool SCALE_IN_CHAIN = AUXM == 1 || (AUXM == 2 && SAMPLE);      // (the sample pass needs every score final)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1078,6 +1108,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             if (!q_valid) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};     // (p.qn may be the caller's own [nq,128] array)
             qreg[4 * t + 0] = v.x; qreg[4 * t + 1] = v.y; qreg[4 * t + 2] = v.z; qreg[4 * t + 3] = v.w;
         }
+    }
+    bf16x8 qhi[8], qlo[8];            // PF: the query tile as split bf16 operands, k block b = elements 64 h + 8 b .. + 7
+    if (PF) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+            ms_split8(f32x4{qreg[8 * b], qreg[8 * b + 1], qreg[8 * b + 2], qreg[8 * b + 3]},
+                      f32x4{qreg[8 * b + 4], qreg[8 * b + 5], qreg[8 * b + 6], qreg[8 * b + 7]}, qhi[b], qlo[b]);
     }
     float my_qlen = 0.0f;
     if (AUX) my_qlen = (p.qlen != nullptr && q_valid) ? p.qlen[qidx] : 0.0f;
@@ -1281,7 +1318,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     // two youngest"), and requests the one three groups ahead, the first three of the next tile during the last three groups.
     // Same synchronisation with the loader as above, except that a tile is reported as consumed when its last fragment
     // has been requested (group 12 of its own chain) instead of before its chain starts.
-    constexpr bool RING_FRAGS = KL > 16 && !SAMPLE;
+    constexpr bool RING_FRAGS = KL > 16 && !SAMPLE && !PF;
     uint32_t rb0 = lin0, rb1 = lin0;          // lane base of the slot of the current / next tile (the two stages of a pair swap them)
     auto stage_ring = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value;
@@ -1347,8 +1384,66 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
         }
     };
+    // PF stage (compiler-scheduled): tile t is read from its slot during its own stage -- two fragments per k block, split,
+    // three bf16 matrix instructions -- 24 of them per tile instead of 64 fp32 ones at a quarter of the cycles each; the
+    // filter, the lists and the synchronisation with the loader are those of stage_ring.
+    auto stage_pf = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const char *slot = smem + (size_t)(t % LDR_R) * 16384 + 8192 * h + 16 * r;
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b), x1 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 512);
+            bf16x8 ah, al;
+            ms_split8(x0, x1, ah, al);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc, 0, 0, 0);
+        }
+        out = acc;
+#ifdef MS_STAMP
+        {
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bad = bad || !(fabsf(acc[i]) < 1e6f);
+            if (__ballot(bad) != 0 && lane == 0 && p.stamps != nullptr && bid < 4096) {
+                unsigned long long *o = p.stamps + 524288 + ((size_t)bid * 8 + wave) * 8;
+                if (o[0] == 0) {
+                    o[0] = 1 + (unsigned long long)t; o[1] = (unsigned long long)ntl; o[2] = (unsigned long long)landed[0]; o[3] = landed_seen;
+                    o[4] = (unsigned long long)consumed[0] | ((unsigned long long)consumed[1] << 32); o[5] = (unsigned long long)consumed[2] | ((unsigned long long)consumed[3] << 32);
+                    o[6] = __ballot(bad); o[7] = __float_as_uint(acc[0]);
+                }
+            }
+        }
+#endif
+        if (!FIRST) {       // tiles t-1 and t have been read (LDS operations execute in order); the loader's counter for the next pair.
+            // The read is a plain volatile one here: in compiler-scheduled code an asm statement whose destination register is
+            // filled later, behind the compiler's back, is a bug waiting for the register allocator (the data of such a read
+            // landed in a register that had been given to the next tile's base address by then).
+            asm volatile("ds_add_u32 %0, %1" ::"v"(cons_addr), "v"(two) : "memory");
+            flag = landed[0];
+        }
+        if (SAMPLE) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) smax = (prev[i] > smax) ? prev[i] : smax;       // (NaN scores never enter)
+        } else {
+            float mx = prev[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, prev[i]);
+            if (__builtin_expect(__ballot(mx > st.tau) != 0, 0)) {
+                float sc[16];
+                uint64_t m[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
+                ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
+            }
+        }
+    };
     auto run_stage = [&](auto first_c, int t, f32x16 &prev, f32x16 &out) __attribute__((always_inline)) {
-        if constexpr (RING_FRAGS) stage_ring(first_c, t, prev, out);
+        if constexpr (PF) stage_pf(first_c, t, prev, out);
+        else if constexpr (RING_FRAGS) stage_ring(first_c, t, prev, out);
         else stage(first_c, t, prev, out);
     };
 
@@ -1361,7 +1456,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #pragma unroll
         for (int i = 0; i < 16; ++i) { acc0[i] = -INFINITY; acc1[i] = -INFINITY; }
         landed_seen = wait_landed(1);
-        if (RING_FRAGS) {
+        if (PF) {
+            // (every stage reads its own tile)
+        } else if (RING_FRAGS) {
             MS_FRAG_READ(areg[0], lin0, 0); MS_FRAG_READ(areg[1], lin0, 512); MS_FRAG_READ(areg[2], lin0, 1024);
         } else {
 #pragma unroll
@@ -1379,7 +1476,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             // shared bound (ScanHist): every 16th tile this query's 16 bucket counters are fetched (sc1: past this CU's L1)
             // while two tiles are multiplied, then the threshold is raised.  The two tests are evaluated separately on purpose
             // (kept apart by the empty asm): carried from one to the other, hipcc keeps the flag in a vector register.
-            if (hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
+            uint32_t hcv[16];            // PF: the same fetch as compiler-visible agent-scope loads (see stage_pf)
+            if (PF && hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
+                const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) hcv[j] = __hip_atomic_load(hp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!PF && hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
                 asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
                              "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
@@ -1392,8 +1495,12 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             asm volatile("" : "+s"(t2));
             if (hist_on && (t2 & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
-                const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
+                if (!PF) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
+                uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
+                if (PF) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) c[j] = hcv[j];
+                }
                 uint32_t cum = 0;
                 int n_lt = 0;
 #pragma unroll
@@ -1505,6 +1612,15 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
     if constexpr (!UB) {                // loader-wave form: its compute waves must fit 256 registers WITHOUT spills (the pinned stage
                                         // cannot tolerate a spill of a register an LDS read is still filling): 32-entry lists get there
                                         // with four fragment registers instead of a tile's sixteen (RING_FRAGS)
+        if constexpr (!AUX) {
+            if (sp.qwb == 4 && sp.prefilter) {          // the prefilter's scan (ms_ip_topk_prefiltered)
+                MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, 0, false, true>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+                hipLaunchKernelGGL((ms_scan_loader_kernel<KL, 0, false, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+                MS_LAUNCH_CHECK("ms_scan_loader_kernel (prefilter)");
+                return MS_OK;
+            }
+        }
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
 #define MS_LAUNCH_LOADER(AUXM)                                                                                           \
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUXM, false>),     \
@@ -1528,6 +1644,15 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
 // Sample pass in the loader-wave form (qwb == 4), values only: one instantiation per mode, whatever the list length.
 template <int AUXM>
 int launch_sample_loader_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    if constexpr (AUXM == 0) {
+        if (sp.prefilter) {
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<5, 0, true, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
+            hipLaunchKernelGGL((ms_scan_loader_kernel<5, 0, true, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+            MS_LAUNCH_CHECK("ms_scan_loader_kernel (prefilter sample)");
+            return MS_OK;
+        }
+    }
     MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<5, AUXM, true>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));
     hipLaunchKernelGGL((ms_scan_loader_kernel<5, AUXM, true>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);

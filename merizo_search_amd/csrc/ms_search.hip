@@ -105,7 +105,8 @@ __global__ __launch_bounds__(256) void ms_prepare_queries_kernel(const float *q,
 constexpr int MERGE_MAX_P = 1024;
 __global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part_s, const uint32_t *part_i, int P,
                                                               int k, int64_t row_offset, float *out_s, int64_t *out_i,
-                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
+                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
+    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *pool = reinterpret_cast<uint2 *>(smem);              // [k*k]
     uint2 *list = pool + (size_t)k * k;                         // [k]
@@ -197,7 +198,8 @@ __global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part
 template <int PER>      // lists per lane: P <= 64 * PER
 __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                           int64_t row_offset, float *out_s, int64_t *out_i,
-                                                          int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
+                                                          int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
+    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ms_head_merge_wave<PER>(reinterpret_cast<uint2 *>(smem), part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0,
                             ub_s, ub_i, blockIdx.x, threadIdx.x);
@@ -209,7 +211,8 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 // the workgroup's first wave.
 __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
-                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i) {
+                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
+    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int q = blockIdx.x, tid = threadIdx.x, kP = k * P;
     uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
 // below the previous one + how many lanes hold it".  -inf when there are fewer than k sampled rows.
 template <int VPL>      // values per lane: ranks * P <= 64 * VPL
 __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb, uint32_t *hist,
-                                                            float *hstep) {
+                                                            float *hstep, const uint32_t *gate, uint32_t gate_epoch) {
+    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     const int q = blockIdx.x, lane = threadIdx.x;
     const float *ps = part_s + (size_t)q * k * P;              // rank-major [k][P]: the first ranks * P floats
     const int count = ranks * P;
@@ -294,6 +298,61 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
             hstep[q] = step;
         }
     }
+}
+
+// ------------------------------------------------------------------ prefilter: exact re-scoring ---
+// ms_ip_topk_prefiltered: the scan ran on APPROXIMATE scores a(row) (split-bf16 matrix instructions, |a - s| <= E =
+// MS_PF_ERR |row| |q|) and kept the kp > k best rows per query by a.  One wave per query re-scores those rows with the exact
+// fp32 chain (the k order of the fp32 scan: s = 0..63: (k = s, k = 64 + s), one fmaf each -- the same bits), takes the
+// best k under the total order, and proves the answer: every row that is NOT a candidate has a <= a_last (the kp-th
+// approximate score), hence s <= a_last + E; if the k-th best exact score is above that, no other row can be in the
+// answer or tie with it.  Otherwise (near-ties by the dozen around the k-th best) the query raises the gate and the exact
+// pipeline, queued behind this kernel, runs after all.
+__global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
+                                                        const int64_t *ai, int64_t row_offset, float err_coef, float *out_s,
+                                                        int64_t *out_i, uint32_t *gate, uint32_t epoch) {
+    __shared__ float qs[128];
+    __shared__ float cs[64];
+    __shared__ uint32_t ci[64];
+    __shared__ float kth;
+    const int q = blockIdx.x, lane = threadIdx.x;
+    qs[lane] = qn[(size_t)q * MS_DIM + lane];
+    qs[64 + lane] = qn[(size_t)q * MS_DIM + 64 + lane];
+    if (lane == 0) kth = -INFINITY;
+    __syncthreads();
+    float qq = qs[lane] * qs[lane] + qs[64 + lane] * qs[64 + lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off);
+    const float qnorm = sqrtf(qq) * 1.001f;
+    const int64_t row = lane < kp ? ai[(size_t)q * kp + lane] : -1;
+    const bool full = ai[(size_t)q * kp + kp - 1] >= 0;
+    const float a_last = as[(size_t)q * kp + kp - 1];
+    float s = -INFINITY;
+    if (row >= 0) {
+        const float4 *x = reinterpret_cast<const float4 *>(db + (size_t)row * MS_DIM);
+        float acc = 0.0f;
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+            const float4 lo = x[t], hi = x[16 + t];
+            acc = fmaf(lo.x, qs[4 * t + 0], acc); acc = fmaf(hi.x, qs[64 + 4 * t + 0], acc);
+            acc = fmaf(lo.y, qs[4 * t + 1], acc); acc = fmaf(hi.y, qs[64 + 4 * t + 1], acc);
+            acc = fmaf(lo.z, qs[4 * t + 2], acc); acc = fmaf(hi.z, qs[64 + 4 * t + 2], acc);
+            acc = fmaf(lo.w, qs[4 * t + 3], acc); acc = fmaf(hi.w, qs[64 + 4 * t + 3], acc);
+        }
+        s = acc;
+    }
+    cs[lane] = s;
+    ci[lane] = row >= 0 ? (uint32_t)row : MS_IDX_NONE;
+    __syncthreads();
+    const int nvalid = __popcll(__ballot(row >= 0));
+    int rank = 0;
+    for (int j = 0; j < kp; ++j) rank += (ci[j] != MS_IDX_NONE && ms_better(cs[j], ci[j], s, ci[lane])) ? 1 : 0;
+    const size_t o0 = (size_t)q * k;
+    if (row >= 0 && rank < k) { out_s[o0 + rank] = s; out_i[o0 + rank] = row_offset + row; }
+    if (lane < k && lane >= nvalid) { out_s[o0 + lane] = -INFINITY; out_i[o0 + lane] = -1; }
+    if (row >= 0 && rank == k - 1) kth = s;
+    __syncthreads();
+    if (lane == 0 && full && !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
 }
 
 // ------------------------------------------------------------------ public k-way merge -
@@ -427,7 +486,7 @@ void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
 // runs with a merge launch instead.
 struct SyncBlock { const void *ws; int dev; char *mem; };
 constexpr int SYNC_BLOCKS = 64;
-constexpr size_t SYNC_BYTES = 256;         // 64 arrival counters of the in-launch merge
+constexpr size_t SYNC_BYTES = 512;         // [0,256) 64 arrival counters of the in-launch merge; [256] the prefilter's gate word
 SyncBlock g_sync[SYNC_BLOCKS];
 int g_sync_used = 0;
 char *sync_block_for(const void *ws) {
@@ -561,6 +620,8 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
+    const uint32_t *gate = sp.gate;
+    const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
     const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
@@ -569,7 +630,7 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
@@ -580,7 +641,7 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
         MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_head_merge_kernel<PER>),                    \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)head_lds));                  \
     hipLaunchKernelGGL(ms_head_merge_kernel<PER>, dim3(nq), dim3(64), head_lds, st, sp.part_s, sp.part_i, pl.P, kp,    \
-                       row_offset, out_s, out_i, out_stride, col0, ub_s, ub_i)
+                       row_offset, out_s, out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch)
         if (per <= 1) { MS_HEAD_MERGE(1); }
         else if (per <= 2) { MS_HEAD_MERGE(2); }
         else if (per <= 4) { MS_HEAD_MERGE(4); }
@@ -592,7 +653,7 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
     }
     const size_t lds = ((size_t)kp * kp + kp) * sizeof(uint2);
     hipLaunchKernelGGL(ms_partial_merge_kernel, dim3(nq), dim3(256), lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset,
-                       out_s, out_i, out_stride, col0, ub_s, ub_i);
+                       out_s, out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch);
     MS_LAUNCH_CHECK("ms_partial_merge_kernel");
     return MS_OK;
 }
@@ -638,6 +699,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
     sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
+    sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -673,7 +735,7 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
         const bool hist_on = pl.qwb == 4 && loader_wave_setting() && hist_setting();
         uint32_t *hist = hist_on ? reinterpret_cast<uint32_t *>(ws + pl.off_hist) : nullptr;
         float *hstep = reinterpret_cast<float *>(ws + pl.off_hstep);
-#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb, hist, hstep)
+#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb, hist, hstep, s0.gate, s0.gate_epoch)
         if (vpl <= 4) { MS_BOUND(4); }
         else if (vpl <= 8) { MS_BOUND(8); }
         else if (vpl <= 16) { MS_BOUND(16); }
@@ -866,6 +928,153 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
         sp.ub_i = ub_i;
     }
     return MS_OK;
+}
+
+// ---- prefiltered search (inner-product modes, >= 3 query tiles, k <= 32) ----------------------------------------------
+// stages: 1 = queries + sample pass + bound, 2 = the scan launch, 4 = merge + exact re-scoring + the gated exact pipeline
+namespace {
+int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 16 ? 32 : (k <= 32 ? 64 : 0))); }
+int prefilter_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_PREFILTER"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the fp32 scan
+    return v;
+}
+std::atomic<uint32_t> g_pf_last_epoch{0};             // epoch of the last prefiltered search (diagnostics)
+uint32_t next_epoch() {                                // never 0: the gate word starts at zero
+    static std::atomic<uint32_t> e{1};
+    uint32_t v = e.fetch_add(1);
+    if (v == 0) v = e.fetch_add(1);
+    return v;
+}
+struct PfLayout { ScanPlan pf, exact; size_t off_as, off_ai, total; int kp; bool ok; };
+PfLayout pf_layout(int64_t n, int nq, int k, int mode) {
+    PfLayout L;
+    L.kp = pf_list_len(k);
+    L.exact = make_plan(n, nq, k, cu_count_cached());
+    L.ok = prefilter_setting() && L.kp > 0 && (mode == MS_MODE_IP_PRENORM || mode == MS_MODE_IP_NORMQ) && n >= 65536 && L.exact.qwb == 4 &&
+           loader_wave_setting() != 0;
+    if (!L.ok) { L.total = L.exact.total; L.off_as = L.off_ai = 0; return L; }
+    L.pf = make_plan(n, nq, L.kp, cu_count_cached());
+    size_t off = L.pf.total > L.exact.total ? L.pf.total : L.exact.total;
+    L.off_as = off; off += ms_align_up((size_t)L.pf.nq_pad * L.kp * sizeof(float), 256);
+    L.off_ai = off; off += ms_align_up((size_t)L.pf.nq_pad * L.kp * sizeof(int64_t), 256);
+    L.total = off;
+    return L;
+}
+int pf_run(int stages, const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
+           float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    int rc = check_search_args(db, n, q, nq, k, mode, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    const PfLayout L = pf_layout(n, nq, k, mode);
+    if (workspace == nullptr || workspace_bytes < L.total)
+        MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_prefiltered: workspace %zu < %zu bytes", workspace_bytes, L.total);
+    char *blk = L.ok && row_norm_bound > 0.0f && row_norm_bound < INFINITY ? sync_block_for(workspace) : nullptr;
+    if (blk == nullptr) {          // shapes the prefilter does not serve: the fp32 path, same stages
+        if (stages == 7) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, out_scores, out_idx, workspace, workspace_bytes, st);
+        if (stages == 1) return ms_ip_topk_prepare(db, n, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, workspace, workspace_bytes, st);
+        if (stages == 2) return ms_ip_topk_scan(db, n, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, workspace, workspace_bytes, st);
+        return ms_ip_topk_finish(n, row_offset, nq, k, out_scores, out_idx, workspace, workspace_bytes, st);
+    }
+    char *ws = (char *)workspace;
+    const ScanPlan &pl = L.pf;
+    ScanParams sp;
+    if (stages & 1) {
+        rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, nullptr, nullptr, 0.0f, ws, st, &sp);
+        if (rc) return rc;
+        sp.prefilter = 1;
+        rc = run_prepass(pl, &sp, nq, ws, st);
+        if (rc) return rc;
+        if (sp.hist != nullptr) hist_mark_clean(workspace, n, nq, L.kp);
+    } else {
+        fill_scan_params(pl, db, n, q, nq, nullptr, nullptr, nullptr, 0.0f, ws, mode, &sp);
+        sp.prefilter = 1;
+        if (pl.prepass_tiles > 0) {
+            sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
+            if (hist_setting()) {
+                sp.hist = reinterpret_cast<uint32_t *>(ws + pl.off_hist);
+                sp.hstep = reinterpret_cast<const float *>(ws + pl.off_hstep);
+                if ((stages & 2) && !hist_take_clean(workspace, n, nq, L.kp))
+                    MS_HIP_CHECK(hipMemsetAsync(sp.hist, 0, (size_t)pl.nq_pad * 16 * sizeof(uint32_t), st));
+            }
+        }
+    }
+    if ((stages & 1) && (stages & 2) && sp.hist != nullptr) (void)hist_take_clean(workspace, n, nq, L.kp);
+    sp.k = pl.k_pass;
+    if (stages & 2) {
+        rc = launch_scan(pl, sp, st);
+        if (rc) return rc;
+    }
+    if (stages & 4) {
+        if (out_scores == nullptr || out_idx == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: NULL outputs");
+        float *as = reinterpret_cast<float *>(ws + L.off_as);
+        int64_t *ai = reinterpret_cast<int64_t *>(ws + L.off_ai);
+        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st);
+        if (rc) return rc;
+        uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
+        const uint32_t epoch = next_epoch();
+        hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, MS_PF_ERR * row_norm_bound,
+                           out_scores, out_idx, gate, epoch);
+        MS_LAUNCH_CHECK("ms_rescore_kernel");
+        g_pf_last_epoch.store(epoch);
+        // the exact pipeline, gated: its launches return at once unless some query raised the gate in ms_rescore_kernel
+        const ScanPlan &px = L.exact;
+        ScanParams sx;
+        fill_scan_params(px, db, n, q, nq, nullptr, nullptr, nullptr, 0.0f, ws, mode, &sx);
+        sx.qn = sp.qn;                       // (the queries prepared for the prefilter: same array, same place)
+        sx.qnorm_eps = 0.0f;
+        sx.gate = gate; sx.gate_epoch = epoch;
+        rc = run_prepass(px, &sx, nq, ws, st);
+        if (rc) return rc;
+        sx.k = px.k_pass;
+        rc = launch_scan(px, sx, st);
+        if (rc) return rc;
+        rc = launch_merge(px, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st);
+        if (rc) return rc;
+    }
+    return MS_OK;
+}
+}  // namespace
+
+size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k) {
+    if (n < 0 || nq < 1 || k < 1) return 0;
+    const size_t a = pf_layout(n, nq, k, MS_MODE_IP_PRENORM).total, b = make_plan(n, nq, k, cu_count_cached()).total;
+    return a > b ? a : b;
+}
+
+int ms_ip_topk_prefiltered(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
+                           float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
+    if (k > 64) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, out_scores, out_idx, workspace, workspace_bytes, stream);
+    return pf_run(7, db, n, row_offset, q, nq, k, mode, row_norm_bound, out_scores, out_idx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ms_ip_topk_prefiltered_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound, void *workspace,
+                                   size_t workspace_bytes, ms_stream_t stream) {
+    return pf_run(1, db, n, 0, q, nq, k, mode, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ms_ip_topk_prefiltered_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound, void *workspace,
+                                size_t workspace_bytes, ms_stream_t stream) {
+    return pf_run(2, db, n, 0, q, nq, k, mode, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+int ms_ip_topk_prefiltered_finish(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
+                                  float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
+    return pf_run(4, db, n, row_offset, q, nq, k, mode, row_norm_bound, out_scores, out_idx, workspace, workspace_bytes, (hipStream_t)stream);
+}
+// Diagnostics for the tests: did the last prefiltered search on this workspace need the exact pipeline?  (synchronises the device)
+int ms_debug_prefilter_gate(void *workspace, unsigned int *gate_value, unsigned int *last_epoch) {
+    char *blk = sync_block_for(workspace);
+    if (blk == nullptr || hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(gate_value, blk + 256, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *last_epoch = (unsigned int)(g_pf_last_epoch.load());
+    return 0;
+}
+
+// Diagnostics (tools/pf_try.py): the candidate lists (approximate scores, rows) the last prefiltered search left in the workspace.
+int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, float *as_host, int64_t *ai_host, int *kp_out) {
+    const PfLayout L = pf_layout(n, nq, k, MS_MODE_IP_PRENORM);
+    if (!L.ok || hipDeviceSynchronize() != hipSuccess) return -1;
+    *kp_out = L.kp;
+    if (hipMemcpy(as_host, (char *)workspace + L.off_as, (size_t)nq * L.kp * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(ai_host, (char *)workspace + L.off_ai, (size_t)nq * L.kp * 8, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return 0;
 }
 
 int ms_topk_merge(const float *scores, const int64_t *idx, int S, int nq, int k, float *out_scores,

@@ -1391,16 +1391,41 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         constexpr bool FIRST = decltype(first_c)::value;
         const char *slot = smem + (size_t)(t % LDR_R) * 16384 + 8192 * h + 16 * r;
         f32x16 acc;
+        if constexpr (KL <= 16) {
+            // all 16 fragments requested up front (their LDS latency overlaps the first blocks), two independent chains (even /
+            // odd k blocks) so that a matrix instruction never waits for the previous one's result
+            f32x4 fr[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int f = 0; f < 16; ++f) fr[f] = *reinterpret_cast<const f32x4 *>(slot + 512 * f);
+            f32x16 acc_a, acc_b;
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const f32x4 x0 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b), x1 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 512);
-            bf16x8 ah, al;
-            ms_split8(x0, x1, ah, al);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc, 0, 0, 0);
+            for (int i = 0; i < 16; ++i) { acc_a[i] = 0.0f; acc_b[i] = 0.0f; }
+#pragma unroll
+            for (int b = 0; b < 8; b += 2) {
+                bf16x8 ah, al, bh2, bl2;
+                ms_split8(fr[2 * b], fr[2 * b + 1], ah, al);
+                ms_split8(fr[2 * b + 2], fr[2 * b + 3], bh2, bl2);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh2, qhi[b + 1], acc_b, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh2, qlo[b + 1], acc_b, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl2, qhi[b + 1], acc_b, 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = acc_a[i] + acc_b[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b), x1 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 512);
+                bf16x8 ah, al;
+                ms_split8(x0, x1, ah, al);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc, 0, 0, 0);
+            }
         }
         out = acc;
 #ifdef MS_STAMP

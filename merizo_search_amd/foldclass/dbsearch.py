@@ -125,7 +125,8 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
     return {"scores": scores, "indices": idx}
 
 
-def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True, raw_queries: bool = False):
+def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True, raw_queries: bool = False,
+              row_norm_bound=None):
     """Exact max-inner-product kNN over a database delivered block by block (knn_exact_faiss,
     dbsearch.py:213-248): per block IndexFlat.add/search -> `I += i0` -> ResultHeap merge.
 
@@ -150,7 +151,8 @@ def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to
         ni = block.shape[0]
         if ni == 0:
             continue
-        s, i = engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries)
+        s, i = (engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries, row_norm_bound=row_norm_bound)
+                if row_norm_bound is not None else engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries))
         if best_s is None:
             best_s, best_i = s, i
         else:
@@ -332,7 +334,9 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
     if shard is not None:
         # resident shard: F.normalize (:303-304) + knn_exact_faiss (:213-248) as ONE call -- for the few queries of a CLI
         # search that is one launch (normalisation in the scan's prologue, merge by its last workgroup)
-        Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False, raw_queries=True)
+        # (more than 64 queries: the prefiltered search, with the shard's row-norm bound measured once when it became resident)
+        Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False, raw_queries=True,
+                           row_norm_bound=target_dict["_resident"].get("row_norm_bound"))
     else:
         logger.info("database shard of %d rows exceeds the resident budget: streaming blocks of %d rows"
                     % (hi - lo, int(search_batchsize)))
@@ -406,6 +410,8 @@ def _resident_shard(target_dict: dict, engine, dbmm, lo: int, hi: int, nq: int, 
     if (hi - lo) * dbmm.shape[1] * 4 > engine.resident_budget(nq, k):
         return None
     cache.update(engine=engine, span=(lo, hi), shard=engine.upload_rows(dbmm, lo, hi))
+    if hasattr(engine, "row_norm_bound"):           # (the CPU oracle engine of the tests has no prefiltered search)
+        cache["row_norm_bound"] = engine.row_norm_bound(cache["shard"])
     return cache["shard"]
 
 

@@ -57,6 +57,7 @@ class HipEngine:
         self._encoder = None
         self._state_dict = state_dict
         self._ws = ops.TopKWorkspace(self.device)
+        self._pws = ops.PrefilterWorkspace(self.device)
 
     # -- encoder ---------------------------------------------------------------------
     def load_weights(self, state_dict: dict) -> None:
@@ -108,9 +109,21 @@ class HipEngine:
         return self._ops.ip_topk(rows, q, k, mode=self._ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
                                  row_offset=row_offset, workspace=self._ws)
 
-    def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False):
+    def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False, row_norm_bound=None):
+        """index.search of dbsearch.py:234-242.  row_norm_bound: an upper bound on the rows' L2 norms when the caller knows one
+        (`row_norm_bound(db)` once per resident database): batches of more than 64 queries then take the prefiltered search
+        (ms_ip_topk_prefiltered: same results bit for bit, the rows scanned with bf16 matrix instructions on split operands)."""
         mode = self._ops.MODE_IP_NORMQ if normalize_queries else self._ops.MODE_IP_PRENORM
+        if row_norm_bound is not None and q.shape[0] > 64 and k <= 32:
+            return self._ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws)
         return self._ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
+
+    def row_norm_bound(self, db) -> float:
+        """max |row| over a resident database, a hair up (one HBM pass; the prefiltered search's error bound scales with it)."""
+        if db.shape[0] == 0:
+            return 1.0
+        inv_min = float(self._ops.row_inv_norms(db, 1e-30).min())
+        return (1.0 / inv_min) * (1.0 + 1e-6) if inv_min > 0.0 else float("inf")
 
     def topk_merge(self, scores, idx):
         return self._ops.topk_merge(scores, idx)

@@ -1,0 +1,16 @@
+"""One prefiltered search shape in a loop (for rocprofv3): python3 tools/pf_loop.py ROWS NQ K [ITERS]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+n, nq, k = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 100
+d = syn.device_database(n, 0, 0, "cuda:0", normalize=True)
+q_raw = torch.randn(nq, 128, device="cuda") * 3
+ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+out = (torch.empty(nq, k, device="cuda"), torch.empty(nq, k, dtype=torch.int64, device="cuda"))
+for _ in range(30): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(iters): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
+torch.cuda.synchronize(); print(f"n={n} nq={nq} k={k}: {(time.perf_counter()-t0)/iters*1e3:.4f} ms per search, fell back: {ops.prefilter_fell_back(ws)}")

@@ -7,17 +7,26 @@ from merizo_search_amd.foldclass import synthetic as syn
 
 lib = _lib.load()
 lib.ms_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+PF = os.environ.get("STAMP_PF") == "1"       # the prefiltered search's scan instead of the fp32 one
 cases = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]] or [(1_000_000, 256, 10), (4_000_000, 256, 10)]
 for n, nq, k in cases:
     d = syn.device_database(n, 0, 0, "cuda:0", normalize=True)
     qq = torch.randn(nq, 128, device="cuda"); qq = qq / qq.norm(dim=1, keepdim=True)
-    ws = ops.TopKWorkspace(d.device).get(n, nq, k)
+    ws = (ops.PrefilterWorkspace if PF else ops.TopKWorkspace)(d.device).get(n, nq, k)
     out_s = torch.empty(nq, k, device="cuda"); out_i = torch.empty(nq, k, dtype=torch.int64, device="cuda")
+    if PF:
+        prep = lambda: ops.ip_topk_prefiltered_stage("prepare", d, qq, k, ws)
+        scan = lambda: ops.ip_topk_prefiltered_stage("scan", d, qq, k, ws)
+        fin = lambda: ops.ip_topk_prefiltered_stage("finish", d, qq, k, ws, out=(out_s, out_i))
+    else:
+        prep = lambda: ops.ip_topk_prepare(d, qq, k, ws)
+        scan = lambda: ops.ip_topk_scan(d, qq, k, ws)
+        fin = lambda: ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
     for _ in range(30):      # warm clocks
-        ops.ip_topk_prepare(d, qq, k, ws); ops.ip_topk_scan(d, qq, k, ws); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+        prep(); scan(); fin()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ops.ip_topk_prepare(d, qq, k, ws); e0.record(); ops.ip_topk_scan(d, qq, k, ws); e1.record(); torch.cuda.synchronize()
+    prep(); e0.record(); scan(); e1.record(); torch.cuda.synchronize()
     words = 8 * 8 * 4096
     buf = np.zeros(words, dtype=np.uint64)
     assert lib.ms_debug_stamps(buf.ctypes.data, words) == 0

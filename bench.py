@@ -53,6 +53,7 @@ sys.path.insert(0, REPO)
 
 MFMA_F32_PEAK = 157.3e12     # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 HBM_PEAK = 8.0e12            # same guide, "HBM3E peak BW" (spec)
+MFMA_BF16_PEAK = 2.5e15      # same guide, dense bf16 matrix peak
 C4_ROWS_PER_GPU = 45_625_000
 C4_NQ = 4096
 
@@ -69,12 +70,32 @@ def small_batch_note(nq):
              "sample pass + bound + scan (normalise in its prologue) + merge launches"))
 
 
-def roofline(nq, rows, k, scan_ms, step_ms):
-    """Both roofs for one scan launch over `rows` rows; the binding one is `frac`."""
+def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
+    """Both roofs for one scan launch over `rows` rows; the binding one is `frac`.
+    prefiltered: the scan of ms_ip_topk_prefiltered scores with bf16 matrix instructions (3 per fp32 one's worth of k), far
+    below the bf16 matrix roof; what is left to bound it is the one read of the rows: the HBM roof."""
     flops = 2.0 * 128 * nq * rows
     bytes_ = 512.0 * rows
     t = scan_ms * 1e-3
     mfma_frac, hbm_frac = flops / t / MFMA_F32_PEAK, bytes_ / t / HBM_PEAK
+    if prefiltered:
+        # three bf16 matrix instructions' worth of flops per fp32 one: T_bf16 = 3 * flops / 2.5e15 against T_hbm: matrix-bound from 208 queries
+        bf16_frac = 3.0 * flops / t / MFMA_BF16_PEAK
+        if nq >= 208:
+            roof = {"bound": "mfma", "achieved": 3.0 * flops / t / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": bf16_frac,
+                    "step_frac": 3.0 * flops / (step_ms * 1e-3) / MFMA_BF16_PEAK}
+        else:
+            roof = {"bound": "hbm", "achieved": bytes_ / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac,
+                    "step_frac": bytes_ / (step_ms * 1e-3) / HBM_PEAK}
+        roof.update({"traffic": None,
+                     "kernel": "ms_scan_loader_kernel<KL, 0, false, true> (prefilter: split-bf16 scores; ms_rescore_kernel makes them exact)",
+                     "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "bf16_mfma_frac": bf16_frac, "fp32_mfma_equivalent_frac": mfma_frac,
+                     "rows_per_launch": rows, "algorithmic_bytes_per_launch": bytes_, "algorithmic_flops_per_launch": 3.0 * flops,
+                     "note": "peak = the dense bf16 matrix peak (the scan issues 3 bf16 matrix instructions per 16 dimensions: hi.hi, hi.lo, lo.hi); "
+                             "bound in practice by vector-instruction issue: every compute wave splits the tile's floats into bf16 hi / lo "
+                             "itself, ~230 vector instructions per 24 matrix instructions (DESIGN.md 5.5); fp32_mfma_equivalent_frac = the "
+                             "fp32 scan's flops over this launch's time against the fp32 matrix peak (> 1: no fp32-matrix kernel can be this fast)"})
+        return roof
     if nq >= 39:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": mfma_frac,
                 "step_frac": flops / (step_ms * 1e-3) / MFMA_F32_PEAK}
@@ -105,7 +126,7 @@ def attach_committed_traffic(roof, pmc_name):
 class SearchBench:
     """One shard resident on this rank + a query batch; `step()` is the timed unit."""
 
-    def __init__(self, torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=False):
+    def __init__(self, torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=False, prefilter=True):
         self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
         self.n_total, self.lo, self.n_local, self.nq, self.k = n_total, lo, hi - lo, nq, k
         self.exchange = exchange or world > 1
@@ -126,7 +147,11 @@ class SearchBench:
         if mine.any():
             self.db[(flat[mine] - lo).to(dev)] = near.reshape(-1, 128)[mine].to(dev)
         self.q = torch.empty_like(self.q_raw)
-        self.ws = torch.empty_like(ops.TopKWorkspace(dev).get(self.n_local, nq, k))
+        # more than 64 queries, k <= 32: the prefiltered search (same results bit for bit: ms_ip_topk_prefiltered), as the driver
+        # runs it on a resident shard; its error bound needs the largest row norm, measured once here as the driver does
+        self.prefilter = prefilter and nq > 64 and k <= 32 and self.n_local >= 65536
+        self.row_norm_bound = (float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)) if self.prefilter else None
+        self.ws = torch.empty_like((ops.PrefilterWorkspace if self.prefilter else ops.TopKWorkspace)(dev).get(self.n_local, nq, k))
         self.ex = sharded.PackedExchange(nq, k, dev)     # this rank's results are written straight into its all-gather block
 
     def step(self, events=None):
@@ -144,6 +169,20 @@ class SearchBench:
                 return ex.merge()
             return ex.out_s, ex.out_i
         ops.l2_normalize_rows(self.q_raw, 1e-12, out=self.q)                # F.normalize of the batch's raw embeddings (dbsearch.py:303-304)
+        if self.prefilter:
+            b = self.row_norm_bound
+            ops.ip_topk_prefiltered_stage("prepare", self.db, self.q, self.k, self.ws, b)       # sample pass on approximate scores
+            if events is not None:
+                events[0].record()
+            ops.ip_topk_prefiltered_stage("scan", self.db, self.q, self.k, self.ws, b)          # dominant kernel: ONE scan launch
+            if events is not None:
+                events[1].record()
+            # merge of the candidate lists, exact re-scoring + proof, and the (gated: normally empty) exact pipeline
+            ops.ip_topk_prefiltered_stage("finish", self.db, self.q, self.k, self.ws, b, out=(ex.out_s, ex.out_i), row_offset=self.lo)
+            if self.exchange:
+                ex.exchange()
+                return ex.merge()
+            return ex.out_s, ex.out_i
         ops.ip_topk_prepare(self.db, self.q, self.k, self.ws)               # sample pass (lower bound per query)
         if events is not None:
             events[0].record()
@@ -162,12 +201,12 @@ class SearchBench:
             self.dist.barrier()
         self.torch.cuda.synchronize()
 
-    def run(self, steps, warmup, prep_budget_s=0.3):
+    def run(self, steps, warmup, prep_budget_s=0.3, max_prep=40):
         """-> (seconds for `steps` steps [max over ranks], mean scan-launch ms [max over ranks], last result)."""
         torch = self.torch
         self.step(); self.fence()
         t = time.perf_counter(); self.step(); self.fence(); est = time.perf_counter() - t
-        for _ in range(min(40, int(prep_budget_s / max(est, 1e-4)))):       # untimed preparation, like the data generation:
+        for _ in range(min(max_prep, int(prep_budget_s / max(est, 1e-4)))):       # untimed preparation, like the data generation:
             self.step()                                                     # the GPU leaves its idle clocks within ~20 launches
         for _ in range(warmup):
             res = self.step()
@@ -393,6 +432,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip hbm_regime / c4_shard / embed")
+    ap.add_argument("--no-prefilter", action="store_true", help="time the fp32 scan (ms_ip_topk) instead of the prefiltered search")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
     args = ap.parse_args()
@@ -450,16 +490,17 @@ def main():
     lo, hi = sharded.shard_bounds(n_total, world, rank)
     log = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
 
-    bench = SearchBench(torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=args.exercise_exchange)
+    bench = SearchBench(torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=args.exercise_exchange,
+                        prefilter=not args.no_prefilter)
     steps = args.steps
     elapsed, scan_ms, res = bench.run(steps, args.warmup)
     checks = bench.check(res, sharded)
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
-        roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
+        roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step, prefiltered=bench.prefilter)
         if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10):
-            attach_committed_traffic(roof, "r03_c2_pmc.json")
+            attach_committed_traffic(roof, "r03_pf_c2_pmc.json" if bench.prefilter else "r03_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
         elif weak:
@@ -479,16 +520,38 @@ def main():
                                        "rate grows N-fold); compare with c4_shard of the N=1 run" if weak else None},
             "row_queries_per_s": float(n_total) * nq * steps / elapsed,
             "roofline": roof,
+            "prefilter": {"used": bool(bench.prefilter),
+                          "exact_pipeline_ran": bool(ops.prefilter_fell_back(bench.ws)) if bench.prefilter else None,
+                          "note": "ms_ip_topk_prefiltered: rows scanned once with bf16 matrix instructions on operands split in registers, "
+                                  "the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, the exact fp32 "
+                                  "pipeline queued behind (it ran only if exact_pipeline_ran); results bit-identical to the fp32 scan "
+                                  "(tests/test_prefilter_gpu.py); the fp32 scan itself: entry fp32_path"},
         }
         line.update(checks)
     else:
         line = None
 
+    if world == 1 and rank == 0:
+        if bench.prefilter:
+            # the same step through the fp32 scan (ms_ip_topk_prepare / _scan / _finish): the kernel the MFMA roofline of rounds 1-3 is about
+            b32 = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, k, prefilter=False)
+            torch.cuda.synchronize(); time.sleep(1.5)       # (the prefiltered steps leave the GPU at a lower clock for a moment)
+            el, sc, r32 = b32.run(100, 10, prep_budget_s=1.0, max_prep=1000)
+            ms32 = el / 100 * 1e3
+            line["fp32_path"] = {"workload": line["config"]["workload"] + " -- fp32 scan, no prefilter", "ms_per_step": ms32, "queries_per_s": nq / ms32 * 1e3,
+                                 "identical_to_prefiltered": bool(torch.equal(r32[1], res[1]) and torch.equal(r32[0].view(torch.int32), res[0].view(torch.int32))),
+                                 "roofline": roofline(nq, n_total, k, sc, ms32)}
+            if (n_total, nq, k) == (1_000_000, 256, 10):
+                attach_committed_traffic(line["fp32_path"]["roofline"], "r03_c2_pmc.json")
+            log("fp32_path: %.4f ms per step, scan %.1f us = %.1f%% of fp32 MFMA peak; identical to the prefiltered results: %s" % (
+                ms32, sc * 1e3, line["fp32_path"]["roofline"]["frac"] * 100, line["fp32_path"]["identical_to_prefiltered"]))
+            del b32, r32
+
     extras_sd, extras_coords = None, None
     if world == 1 and not args.no_extras:
         db_keep, q_keep = bench.db, bench.q_raw
         del bench.ws
-        mk = lambda rows, nq_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k)
+        mk = lambda rows, nq_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k, prefilter=not args.no_prefilter)
         line["hbm_regime"] = hbm_regime(mk, (1_000_000, 4_000_000), log)
         free, _tot = torch.cuda.mem_get_info(dev)
         if free > 40 << 30:
@@ -500,10 +563,22 @@ def main():
             line["c4_shard"] = {"workload": "one rank's share of C4: %d x 128 rows x %d queries, top-%d" % (C4_ROWS_PER_GPU, C4_NQ, k),
                                 "ms_per_step": ms4, "queries_per_s": C4_NQ / ms4 * 1e3, "planted_recall": planted4,
                                 "note": "queries_per_s here = the N-GPU rate on an N x 45.6M-row database, minus the all-gather + merge of 480 KB per rank",
-                                "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
-            if k == 10:
-                attach_committed_traffic(line["c4_shard"]["roofline"], "r03_c4_pmc.json")
-            log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s, scan %.1f%% of fp32 MFMA peak" % (ms4, C4_NQ / ms4 * 1e3, line["c4_shard"]["roofline"]["frac"] * 100))
+                                "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4, prefiltered=big.prefilter),
+                                "prefiltered": bool(big.prefilter),
+                                "exact_pipeline_ran": bool(ops.prefilter_fell_back(big.ws)) if big.prefilter else None}
+            log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (%s), scan %.1f ms" % (ms4, C4_NQ / ms4 * 1e3, "prefiltered" if big.prefilter else "fp32 scan", sc))
+            if big.prefilter:       # the fp32 scan on the same shard
+                big.prefilter = False
+                big.ws = torch.empty_like(ops.TopKWorkspace(dev).get(big.n_local, C4_NQ, k))
+                el, sc, r4f = big.run(2, 1, prep_budget_s=0.0)
+                ms4f = el / 2 * 1e3
+                line["c4_shard"]["fp32_path"] = {"ms_per_step": ms4f, "queries_per_s": C4_NQ / ms4f * 1e3, "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4f),
+                                                 "identical_to_prefiltered": bool(torch.equal(r4f[1], r4[1]) and torch.equal(r4f[0].view(torch.int32), r4[0].view(torch.int32)))}
+                if k == 10:
+                    attach_committed_traffic(line["c4_shard"]["fp32_path"]["roofline"], "r03_c4_pmc.json")
+                log("c4_shard fp32 path: %.1f ms per batch, scan %.1f%% of fp32 MFMA peak, identical: %s" % (
+                    ms4f, line["c4_shard"]["fp32_path"]["roofline"]["frac"] * 100, line["c4_shard"]["fp32_path"]["identical_to_prefiltered"]))
+                del r4f
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
             small = []
             for nq_ in (1, 4, 8, 32):
@@ -528,10 +603,10 @@ def main():
         # per lane, k <= 64 the non-loader kernel with 32)
         line["k_sweep"] = []
         for kk in (1, 10, 20, 32, 64):
-            bk = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, kk)
+            bk = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, kk, prefilter=not args.no_prefilter)
             el, sc, _ = bk.run(40, 5, prep_budget_s=0.05)
             line["k_sweep"].append({"k": kk, "ms_per_step": el / 40 * 1e3, "scan_ms": sc, "queries_per_s": nq * 40 / el,
-                                    "kernel": scan_kernel_name(nq, kk)})
+                                    "kernel": scan_kernel_name(nq, kk), "prefiltered": bool(bk.prefilter)})
             log("k_sweep k=%d: %.3f ms per step (scan %.3f ms)" % (kk, el / 40 * 1e3, sc))
             del bk
         line["c3_search"] = c3_search_bench(torch, ops, syn, dev, k, log)

@@ -926,14 +926,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MS_PF_ERR 2.5e-4f
 __device__ __forceinline__ void ms_split8(const f32x4 &x0, const f32x4 &x1, bf16x8 &hi, bf16x8 &lo) {
     typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     u32x4_ H, L;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const uint32_t a = __float_as_uint(x[2 * i]), b = __float_as_uint(x[2 * i + 1]);
         H[i] = __builtin_amdgcn_perm(b, a, 0x07060302u);            // upper halves of b : a
-        const float la = x[2 * i] - __uint_as_float(a & 0xFFFF0000u), lb = x[2 * i + 1] - __uint_as_float(b & 0xFFFF0000u);
-        L[i] = __builtin_amdgcn_perm(__float_as_uint(lb), __float_as_uint(la), 0x07060302u);
+        // x - hi for the pair in one packed subtraction (v_pk_add_f32 with the second operand negated)
+        const f32x2_ xv = {x[2 * i], x[2 * i + 1]};
+        const f32x2_ tv = {__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u)};
+        const f32x2_ lv = xv - tv;
+        L[i] = __builtin_amdgcn_perm(__float_as_uint(lv.y), __float_as_uint(lv.x), 0x07060302u);
     }
     hi = __builtin_bit_cast(bf16x8, H);
     lo = __builtin_bit_cast(bf16x8, L);
@@ -992,7 +996,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs back to back, so it
         // is written to need as few instructions as possible: raised priority, and every LDS-DMA piece is one s_mov m0 +
         // one global_load_lds with an SGPR base, ONE lane-offset register and an immediate (inline asm).
-        __builtin_amdgcn_s_setprio(3);
+#ifndef MS_PF_LOADER_PRIO
+#define MS_PF_LOADER_PRIO 3
+#endif
+        if (PF) __builtin_amdgcn_s_setprio(MS_PF_LOADER_PRIO); else __builtin_amdgcn_s_setprio(3);
         // piece `it` -> LDS bytes [it * 1024, it * 1024 + 1024) of the slot = chunks 2 it (lanes 0-31) and 2 it + 1 (lanes 32-63)
         // of rows r = lane & 31: source byte r * 512 + (2 it + h) * 16 = voff + 32 it
         const uint32_t voff_full = (uint32_t)(r * 512 + h * 16);

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 // pipeline, queued behind this kernel, runs after all.
 __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
                                                         const int64_t *ai, int64_t row_offset, float err_coef, float *out_s,
-                                                        int64_t *out_i, uint32_t *gate, uint32_t epoch) {
+                                                        int64_t *out_i, uint32_t *gate, uint32_t epoch, float *exact_lb) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -352,7 +352,10 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     if (lane < k && lane >= nvalid) { out_s[o0 + lane] = -INFINITY; out_i[o0 + lane] = -1; }
     if (row >= 0 && rank == k - 1) kth = s;
     __syncthreads();
-    if (lane == 0 && full && !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
+    if (lane == 0) {
+        exact_lb[q] = kth;      // k rows score at least this: the bound the exact scan starts from, should it have to run (-inf: none)
+        if (full && !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
+    }
 }
 
 // ------------------------------------------------------------------ public k-way merge -
@@ -933,7 +936,9 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
 // ---- prefiltered search (inner-product modes, >= 3 query tiles, k <= 32) ----------------------------------------------
 // stages: 1 = queries + sample pass + bound, 2 = the scan launch, 4 = merge + exact re-scoring + the gated exact pipeline
 namespace {
-int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 16 ? 32 : (k <= 32 ? 64 : 0))); }
+// candidates kept per query: twice k for short lists, at least 8-16 spare entries for long ones (the proof needs the rows within the
+// error bound of the k-th best to fit; more spare entries = fewer runs of the exact pipeline on clustered data)
+int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 24 ? 32 : (k <= 48 ? 64 : 0))); }
 int prefilter_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_PREFILTER"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the fp32 scan
@@ -1012,19 +1017,21 @@ int pf_run(int stages, const float *db, int64_t n, int64_t row_offset, const flo
         if (rc) return rc;
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
         const uint32_t epoch = next_epoch();
+        const ScanPlan &px = L.exact;
+        float *exact_lb = reinterpret_cast<float *>(ws + px.off_lb_s);
         hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, MS_PF_ERR * row_norm_bound,
-                           out_scores, out_idx, gate, epoch);
+                           out_scores, out_idx, gate, epoch, exact_lb);
         MS_LAUNCH_CHECK("ms_rescore_kernel");
         g_pf_last_epoch.store(epoch);
-        // the exact pipeline, gated: its launches return at once unless some query raised the gate in ms_rescore_kernel
-        const ScanPlan &px = L.exact;
+        // the exact pipeline, gated: its two launches return at once unless some query raised the gate in ms_rescore_kernel.  No
+        // sample pass: the k-th best exact score among a query's candidates is already a lower bound on its k-th best (k rows
+        // score at least that), and a tight one.
         ScanParams sx;
         fill_scan_params(px, db, n, q, nq, nullptr, nullptr, nullptr, 0.0f, ws, mode, &sx);
         sx.qn = sp.qn;                       // (the queries prepared for the prefilter: same array, same place)
         sx.qnorm_eps = 0.0f;
         sx.gate = gate; sx.gate_epoch = epoch;
-        rc = run_prepass(px, &sx, nq, ws, st);
-        if (rc) return rc;
+        sx.lb_s = exact_lb;
         sx.k = px.k_pass;
         rc = launch_scan(px, sx, st);
         if (rc) return rc;

@@ -10,7 +10,7 @@ d = syn.device_database(n, 0, 0, "cuda:0", normalize=True)
 q_raw = torch.randn(nq, 128, device="cuda") * 3
 ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
 out = (torch.empty(nq, k, device="cuda"), torch.empty(nq, k, dtype=torch.int64, device="cuda"))
-for _ in range(30): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
+for _ in range(3 if n > 20_000_000 else 30): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(iters): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
 torch.cuda.synchronize(); print(f"n={n} nq={nq} k={k}: {(time.perf_counter()-t0)/iters*1e3:.4f} ms per search, fell back: {ops.prefilter_fell_back(ws)}")

@@ -18,8 +18,16 @@ of 12*nq*k bytes per rank and one merge per step.  queries/s is then (nearly) co
 database grows N-fold; the N = 1 point of that curve is the `c4_shard` entry of the default run.
 `--rows R` overrides either default with R total rows sharded over the ranks (strong scaling).
 
+More than 64 queries and k <= 32 (the headline and c4_shard): the step runs the PREFILTERED search (ms_ip_topk_prefiltered: the
+rows scanned once with bf16 matrix instructions on operands split in registers, the best 2k rows per query re-scored with
+the exact fp32 chain, the answer proved complete per query, the exact fp32 pass gated behind it) -- bit-identical results;
+`fp32_path` times the same step through the fp32 scan and checks the two results against each other; `--no-prefilter` makes
+the fp32 scan the headline.
+
 One JSON line is printed by rank 0 (contract in the task statement), with
-  roofline      dominant kernel (ms_scan_loader_kernel; ms_scan_kernel below 3 query tiles):
+  roofline      dominant kernel.  Prefiltered: its scan launch against the dense bf16 matrix peak (3 bf16 matrix instructions'
+                flops per dimension block) from 208 queries, against the HBM peak below.  fp32 scan
+                (ms_scan_loader_kernel; ms_scan_kernel below 3 query tiles):
                 algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the scan
                 launch against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic
                 bytes (512 B per row) against the 8 TB/s HBM peak; both fractions always included,

@@ -31,6 +31,10 @@ for c in range(ncases):
             s, i = ops.ip_topk(torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda(), k, mode=ops.MODE_COSINE_RAW, **kw)
             sr, ir = orc.cosine_topk(db, q, k, lengths if use_mask else None, qlen if use_mask else None, mincov)
             assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), sr, ir, tol=2e-6)
+            # the product's form: rows normalised once, MS_MODE_COSINE_UNIT
+            unit = ops.l2_normalize_rows_(torch.from_numpy(db).cuda(), 1e-8)
+            s, i = ops.ip_topk(unit, torch.from_numpy(q).cuda(), k, mode=ops.MODE_COSINE_UNIT, **kw)
+            assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), sr, ir, tol=2e-6)
         else:
             db = syn.normalized_database(n, seed)
             q = syn.normalized_database(nq, seed + 1)
@@ -40,6 +44,16 @@ for c in range(ncases):
             sr, ir = orc.ip_topk(db, q, k, row_offset=off, order=1)
             assert np.array_equal(i.cpu().numpy(), ir), "indices"
             assert np.array_equal(s.cpu().numpy().view(np.uint32), sr.view(np.uint32)), "score bits"
+            # the prefiltered search (takes the plain path itself for the shapes it does not serve): same bits; with a few
+            # clusters of near-duplicates of a query planted now and then, so that the gated exact pass runs too
+            if rng.integers(0, 3) == 0 and n > 1000:
+                rows = rng.integers(0, n, size=min(n, 200))
+                v = q[0][None, :] + rng.normal(0, 3e-7, size=(len(rows), 128)).astype(np.float32)
+                db[rows] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+                sr, ir = orc.ip_topk(db, q, k, row_offset=off, order=1)
+            s, i = ops.ip_topk_prefiltered(torch.from_numpy(db).cuda(), torch.from_numpy(q).cuda(), k, 1.0 + 1e-6, row_offset=off)
+            assert np.array_equal(i.cpu().numpy(), ir), "prefiltered: indices"
+            assert np.array_equal(s.cpu().numpy().view(np.uint32), sr.view(np.uint32)), "prefiltered: score bits"
     except AssertionError as e:
         bad += 1
         print("MISMATCH", dict(n=n, nq=nq, k=k, cosine=cosine, seed=seed), str(e)[:200])

@@ -1404,6 +1404,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             f32x4 fr[16];
 #pragma unroll
             for (int f = 0; f < 16; ++f) fr[f] = *reinterpret_cast<const f32x4 *>(slot + 512 * f);
+            if constexpr (KL <= 10) __builtin_amdgcn_sched_barrier(0);      // (hipcc would otherwise request four at a time and wait for each
+                                                                            //  batch; with 16-entry lists the registers do not allow it)
             f32x16 acc_a, acc_b;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { acc_a[i] = 0.0f; acc_b[i] = 0.0f; }

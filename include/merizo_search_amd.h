@@ -129,6 +129,9 @@ int ms_ip_topk_prefiltered_finish(const float *db, int64_t n, int64_t row_offset
 /* Diagnostics (tests): synchronises the device; *gate_value == *last_epoch means the last prefiltered search on this
  * workspace needed the exact pipeline. */
 int ms_debug_prefilter_gate(void *workspace, unsigned int *gate_value, unsigned int *last_epoch);
+/* Diagnostics (tools/pf_debug.py): the candidate lists of the last prefiltered search on this workspace, copied to the host
+ * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); -1 when the shape is not served by the prefilter. */
+int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, float *as_host, int64_t *ai_host, int *kp_out);
 
 /* Merge S sorted result lists per query into the best k: faiss.ResultHeap(nq,k).add_result /
  * finalize (dbsearch.py:224,240,245) and the cross-shard merge after the RCCL all-gather.

@@ -53,6 +53,7 @@ SIGNATURES = {
     "ms_ip_topk_prefiltered_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _f, _vp, _sz, _vp]),
     "ms_ip_topk_prefiltered_finish": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _sz, _vp]),
     "ms_debug_prefilter_gate": (_int, [_vp, _vp, _vp]),
+    "ms_debug_prefilter_lists": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge_strided": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_egnn_weight_floats": (_sz, []),

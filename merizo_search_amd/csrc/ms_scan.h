@@ -996,10 +996,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // The loader shares a SIMD (and its vector issue port) with a compute wave that issues MFMAs back to back, so it
         // is written to need as few instructions as possible: raised priority, and every LDS-DMA piece is one s_mov m0 +
         // one global_load_lds with an SGPR base, ONE lane-offset register and an immediate (inline asm).
-#ifndef MS_PF_LOADER_PRIO
-#define MS_PF_LOADER_PRIO 3
-#endif
-        if (PF) __builtin_amdgcn_s_setprio(MS_PF_LOADER_PRIO); else __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);
         // piece `it` -> LDS bytes [it * 1024, it * 1024 + 1024) of the slot = chunks 2 it (lanes 0-31) and 2 it + 1 (lanes 32-63)
         // of rows r = lane & 31: source byte r * 512 + (2 it + h) * 16 = voff + 32 it
         const uint32_t voff_full = (uint32_t)(r * 512 + h * 16);
@@ -1047,7 +1044,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #ifdef MS_ABL_NODMA
 #define MS_PIECE(IT)
 #else
-#define MS_PIECE(IT) ms_glds_s16<32 * (IT)>(slot_lds + (IT) * 1024, voff, sb);
+            // (prefilter: 64 idle cycles behind every piece -- a burst of 16 VMEM instructions holds the SIMD's vector issue port
+            //  against the compute wave it shares with, whose stage is vector-issue bound there: 4-6 % of the call; the fp32 stage,
+            //  bound by the matrix pipe, is faster with the burst)
+#define MS_PIECE(IT) ms_glds_s16<32 * (IT)>(slot_lds + (IT) * 1024, voff, sb); if (PF) __builtin_amdgcn_s_sleep(1);
 #endif
             MS_PIECE(0) MS_PIECE(1) MS_PIECE(2) MS_PIECE(3) MS_PIECE(4) MS_PIECE(5) MS_PIECE(6) MS_PIECE(7)
             MS_PIECE(8) MS_PIECE(9) MS_PIECE(10) MS_PIECE(11) MS_PIECE(12) MS_PIECE(13) MS_PIECE(14) MS_PIECE(15)
@@ -1398,6 +1398,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         constexpr bool FIRST = decltype(first_c)::value;
         const char *slot = smem + (size_t)(t % LDR_R) * 16384 + 8192 * h + 16 * r;
         f32x16 acc;
+#ifdef MS_STAMP
+        const unsigned long long pf_t0 = __builtin_amdgcn_s_memtime();
+#endif
         if constexpr (KL <= 16) {
             // all 16 fragments requested up front (their LDS latency overlaps the first blocks), two independent chains (even /
             // odd k blocks) so that a matrix instruction never waits for the previous one's result
@@ -1438,19 +1441,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         }
         out = acc;
 #ifdef MS_STAMP
-        {
-            bool bad = false;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bad = bad || !(fabsf(acc[i]) < 1e6f);
-            if (__ballot(bad) != 0 && lane == 0 && p.stamps != nullptr && bid < 4096) {
-                unsigned long long *o = p.stamps + 524288 + ((size_t)bid * 8 + wave) * 8;
-                if (o[0] == 0) {
-                    o[0] = 1 + (unsigned long long)t; o[1] = (unsigned long long)ntl; o[2] = (unsigned long long)landed[0]; o[3] = landed_seen;
-                    o[4] = (unsigned long long)consumed[0] | ((unsigned long long)consumed[1] << 32); o[5] = (unsigned long long)consumed[2] | ((unsigned long long)consumed[3] << 32);
-                    o[6] = __ballot(bad); o[7] = __float_as_uint(acc[0]);
-                }
-            }
-        }
+        asm volatile("s_nop 0" : "+v"(out));
+        stamp_ins += __builtin_amdgcn_s_memtime() - pf_t0;       // (diagnostics: cycles of the score computation of this stage)
+        stamp_nins += 1;
 #endif
         if (!FIRST) {       // tiles t-1 and t have been read (LDS operations execute in order); the loader's counter for the next pair.
             // The read is a plain volatile one here: in compiler-scheduled code an asm statement whose destination register is

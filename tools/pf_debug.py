@@ -11,7 +11,6 @@ s1, i1 = ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, works
 print("fell back:", ops.prefilter_fell_back(ws))
 lib = _lib.load()
 a_s = np.zeros((nq, 64), np.float32); a_i = np.zeros((nq, 64), np.int64); kp = ctypes.c_int(0)
-lib.ms_debug_prefilter_lists.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
 assert lib.ms_debug_prefilter_lists(ws.data_ptr(), n, nq, k, a_s.ctypes.data, a_i.ctypes.data, ctypes.byref(kp)) == 0
 kp = kp.value
 a_s = a_s.reshape(-1)[:nq * kp].reshape(nq, kp); a_i = a_i.reshape(-1)[:nq * kp].reshape(nq, kp)

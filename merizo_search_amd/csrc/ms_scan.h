@@ -1427,17 +1427,27 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = acc_a[i] + acc_b[i];
         } else {
+            // 32-entry lists: no room for a tile of fragments; two k blocks at a time.  The SAME arithmetic, instruction for
+            // instruction, as above (the sample pass runs the branch above: its bound must hold for these scores bit for bit)
+            f32x16 acc_a, acc_b;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+            for (int i = 0; i < 16; ++i) { acc_a[i] = 0.0f; acc_b[i] = 0.0f; }
 #pragma unroll
-            for (int b = 0; b < 8; ++b) {
+            for (int b = 0; b < 8; b += 2) {
                 const f32x4 x0 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b), x1 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 512);
-                bf16x8 ah, al;
+                const f32x4 x2 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 1024), x3 = *reinterpret_cast<const f32x4 *>(slot + 1024 * b + 1536);
+                bf16x8 ah, al, bh2, bl2;
                 ms_split8(x0, x1, ah, al);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc, 0, 0, 0);
+                ms_split8(x2, x3, bh2, bl2);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qhi[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh2, qhi[b + 1], acc_b, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, qlo[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bh2, qlo[b + 1], acc_b, 0, 0, 0);
+                acc_a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, qhi[b], acc_a, 0, 0, 0);
+                acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bl2, qhi[b + 1], acc_b, 0, 0, 0);
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = acc_a[i] + acc_b[i];
         }
         out = acc;
 #ifdef MS_STAMP

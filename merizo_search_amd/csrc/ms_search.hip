@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 // fp32 chain (the k order of the fp32 scan: s = 0..63: (k = s, k = 64 + s), one fmaf each -- the same bits), takes the
 // best k under the total order, and proves the answer: every row that is NOT a candidate has a <= a_last (the kp-th
 // approximate score), hence s <= a_last + E; if the k-th best exact score is above that, no other row can be in the
-// answer or tie with it.  Otherwise (near-ties by the dozen around the k-th best) the query raises the gate and the exact
+// answer or tie with it (the candidate list must be full for that argument: a list with empty slots raises the gate too).  Otherwise (near-ties by the dozen around the k-th best) the query raises the gate and the exact
 // pipeline, queued behind this kernel, runs after all.
 __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
                                                         const int64_t *ai, int64_t row_offset, float err_coef, float *out_s,
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     __syncthreads();
     if (lane == 0) {
         exact_lb[q] = kth;      // k rows score at least this: the bound the exact scan starts from, should it have to run (-inf: none)
-        if (full && !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
+        // (a list that is not full cannot happen on a database of >= 65,536 rows unless rows were lost to a bound: no proof then either)
+        if (!full || !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
     }
 }
 

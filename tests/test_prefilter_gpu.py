@@ -40,7 +40,7 @@ def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fal
 
 
 @pytest.mark.parametrize("n,nq,k", [(70_000, 65, 1), (70_000, 100, 5), (131_105, 97, 10), (300_000, 256, 10), (262_113, 130, 16),
-                                    (400_000, 200, 20), (200_000, 129, 32), (1_000_003, 256, 10), (100_000, 1000, 3)])
+                                    (400_000, 200, 20), (200_000, 129, 32), (300_000, 100, 40), (1_000_003, 256, 10), (100_000, 1000, 3)])
 def test_prefiltered_is_bit_identical_and_needs_no_exact_pass_on_ordinary_data(n, nq, k, torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops
@@ -85,9 +85,9 @@ def test_prefiltered_near_ties_by_the_hundred_fall_back_to_the_exact_pipeline(to
     assert fell_back
 
 
-@pytest.mark.parametrize("n,nq,k", [(300_000, 40, 10), (300_000, 100, 48), (20_000, 100, 10), (300_000, 100, 100)])
+@pytest.mark.parametrize("n,nq,k", [(300_000, 40, 10), (300_000, 100, 49), (20_000, 100, 10), (300_000, 100, 100)])
 def test_prefiltered_shapes_it_does_not_serve_take_the_plain_path(n, nq, k, torch_gpu):
-    """<= 64 queries, k > 32, small databases: the call is ms_ip_topk (same results, of course)."""
+    """<= 64 queries, k > 48, small databases: the call is ms_ip_topk (same results, of course)."""
     torch = torch_gpu
     from merizo_search_amd import ops
     from oracle import oracle as orc

@@ -111,8 +111,9 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
  * by more than the error bound).  Where the proof fails (dozens of rows within the error bound of the k-th best), the
  * exact fp32 pipeline, queued behind on the same stream, runs for the batch: always exact, never an approximation.
  *   row_norm_bound   an upper bound on the L2 norm of every row of db (1.0 for a database of unit vectors, as
- *                    dbfname_IP holds; 1 / min(ms_row_inv_norms) otherwise); <= 0 or shapes outside the above: the call is
- *                    ms_ip_topk.
+ *                    dbfname_IP holds; 1 / min(ms_row_inv_norms) otherwise); <= 0, not finite (a database with non-finite
+ *                    rows has no bound) or shapes outside the above: the call is ms_ip_topk.  Queries with non-finite
+ *                    elements fail their proof and get the exact pass.
  * Workspace: ms_ip_topk_prefiltered_workspace_bytes.  _prepare / _scan / _finish: its three stages as for ms_ip_topk
  * (queries + sample pass; the one scan launch; merge + exact re-scoring + the gated exact pipeline). */
 size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k);

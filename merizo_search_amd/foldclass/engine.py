@@ -114,7 +114,7 @@ class HipEngine:
         (`row_norm_bound(db)` once per resident database): batches of more than 64 queries then take the prefiltered search
         (ms_ip_topk_prefiltered: same results bit for bit, the rows scanned with bf16 matrix instructions on split operands)."""
         mode = self._ops.MODE_IP_NORMQ if normalize_queries else self._ops.MODE_IP_PRENORM
-        if row_norm_bound is not None and q.shape[0] > 64 and k <= 32:
+        if row_norm_bound is not None and q.shape[0] > 64 and k <= 48:
             return self._ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws)
         return self._ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
 

@@ -128,3 +128,38 @@ def test_engine_uses_the_prefilter_for_large_batches_on_a_resident_database(torc
     s1, i1 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True, row_norm_bound=bound)
     s0, i0 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+def test_prefiltered_shards_merge_to_the_unsharded_answer(torch_gpu):
+    """Two row shards searched through the prefilter (row offsets, the shard's own row-norm bound) + ms_topk_merge == one
+    search over all rows: what dbsearch_faiss does on two ranks."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import engine as eng
+    e = eng.HipEngine("cuda:0")
+    n, nq, k = 400_000, 150, 10
+    db, q = _norm_db(n, seed=461), _norm_db(nq, seed=462)
+    d, dq = _dev(torch, db), _dev(torch, q)
+    s_all, i_all = ops.ip_topk(d, dq, k)
+    parts = []
+    for lo, hi in ((0, 170_000), (170_000, n)):
+        shard = d[lo:hi].contiguous()
+        parts.append(e.ip_topk(shard, dq, k, row_offset=lo, row_norm_bound=e.row_norm_bound(shard)))
+    s, i = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(i, i_all) and torch.equal(s.view(torch.int32), s_all.view(torch.int32))
+
+
+def test_prefiltered_declines_databases_with_non_finite_rows(torch_gpu):
+    """A row with an infinite element has no norm bound: engine.row_norm_bound is not finite and the call is ms_ip_topk."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import engine as eng
+    e = eng.HipEngine("cuda:0")
+    db, q = _norm_db(100_000, seed=471), _norm_db(100, seed=472)
+    db[777, 5] = np.inf
+    d, dq = _dev(torch, db), _dev(torch, q)
+    bound = e.row_norm_bound(d)
+    assert not np.isfinite(bound)
+    s1, i1 = e.ip_topk(d, dq, 10, row_norm_bound=bound)
+    s0, i0 = ops.ip_topk(d, dq, 10)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))

@@ -345,6 +345,8 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
                            to_host=False)
     Ds, Is = sharded.exchange_and_merge(Ds, Is, engine)                   # all-gather + merge; no-op on one rank
     D, I = Ds.cpu().numpy(), Is.cpu().numpy()
+    if hasattr(engine, "prefilter_feedback"):
+        engine.prefilter_feedback(logger)       # (the copy above synchronised: reading the prefilter's gate costs nothing now)
     results = [dict() for _ in range(nq)]
     all_results = [dict() for _ in range(nq)]
     if rank != 0:

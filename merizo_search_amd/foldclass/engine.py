@@ -58,6 +58,7 @@ class HipEngine:
         self._state_dict = state_dict
         self._ws = ops.TopKWorkspace(self.device)
         self._pws = ops.PrefilterWorkspace(self.device)
+        self._pf_enabled, self._pf_fallbacks, self._pf_pending = True, 0, False
 
     # -- encoder ---------------------------------------------------------------------
     def load_weights(self, state_dict: dict) -> None:
@@ -114,9 +115,28 @@ class HipEngine:
         (`row_norm_bound(db)` once per resident database): batches of more than 64 queries then take the prefiltered search
         (ms_ip_topk_prefiltered: same results bit for bit, the rows scanned with bf16 matrix instructions on split operands)."""
         mode = self._ops.MODE_IP_NORMQ if normalize_queries else self._ops.MODE_IP_PRENORM
-        if row_norm_bound is not None and q.shape[0] > 64 and k <= 48:
+        if row_norm_bound is not None and q.shape[0] > 64 and k <= 48 and self._pf_enabled:
+            self._pf_pending = True
             return self._ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws)
         return self._ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
+
+    def prefilter_feedback(self, log=None):
+        """Call at a point where the search results have been copied to the host anyway (no extra synchronisation): did the last
+        prefiltered search need the exact pass as well?  A batch that does costs the prefilter's scan ON TOP of the fp32 one; a
+        database whose best hits are families of near-duplicates (dozens of rows within 2.5e-4 of the k-th best score) would do
+        so batch after batch, so two such batches in a row switch the prefilter off for this engine (the results were exact
+        either way)."""
+        if not getattr(self, "_pf_pending", False) or self._pws.buf is None:
+            return
+        self._pf_pending = False
+        if self._ops.prefilter_fell_back(self._pws.buf):
+            self._pf_fallbacks += 1
+            if self._pf_fallbacks >= 2:
+                self._pf_enabled = False
+                if log is not None:
+                    log.info("prefiltered search: the exact pass was needed twice in a row on this database; using the fp32 scan from now on")
+        else:
+            self._pf_fallbacks = 0
 
     def row_norm_bound(self, db) -> float:
         """max |row| over a resident database, a hair up (one HBM pass; the prefiltered search's error bound scales with it)."""

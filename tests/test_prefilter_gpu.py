@@ -163,3 +163,28 @@ def test_prefiltered_declines_databases_with_non_finite_rows(torch_gpu):
     s1, i1 = e.ip_topk(d, dq, 10, row_norm_bound=bound)
     s0, i0 = ops.ip_topk(d, dq, 10)
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+def test_engine_switches_the_prefilter_off_after_two_batches_that_needed_the_exact_pass(torch_gpu):
+    """foldclass/engine.py: near-duplicate families make every batch run both scans; after two in a row the engine uses the fp32
+    scan for this database.  Results are exact before and after."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import engine as eng
+    e = eng.HipEngine("cuda:0")
+    n, nq, k = 150_000, 96, 10
+    db, q = _norm_db(n, seed=481), _norm_db(nq, seed=482)
+    rng = np.random.default_rng(7)
+    rows = rng.choice(n, size=(nq, 100), replace=False)
+    for j in range(nq):
+        v = q[j][None, :] + rng.normal(0, 2e-7, size=(100, 128)).astype(np.float32)
+        db[rows[j]] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    d, dq = _dev(torch, db), _dev(torch, q)
+    bound = e.row_norm_bound(d)
+    s0, i0 = ops.ip_topk(d, dq, k)
+    for call in range(4):
+        s, i = e.ip_topk(d, dq, k, row_norm_bound=bound)
+        assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+        s.cpu()
+        e.prefilter_feedback()
+        assert e._pf_enabled == (call < 1)

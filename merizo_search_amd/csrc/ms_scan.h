@@ -1303,6 +1303,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #ifdef MS_STAMP
                 const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
+                // Compiler-scheduled code follows, and the fragment registers still have LDS reads in flight (issued by the asm
+                // statements above): everything has to have landed before hipcc may touch -- move, spill to AGPRs -- any of them
+                // (with 32-entry lists it did, a copy taken before the data was there put stale fragments into the next tile:
+                // one run in twenty lost a row somewhere).
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]),
+                             "+v"(areg[6]), "+v"(areg[7]), "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]),
+                             "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]), "+v"(flag) :: "memory");
                 float sc[16];
                 uint64_t m[16];
                 if (AUXM == 2) {            // unit rows: the length mask (dbsearch.py:76,78) is applied here, to the whole tile
@@ -1378,6 +1385,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #ifdef MS_STAMP
             const unsigned long long i0 = __builtin_amdgcn_s_memtime();
 #endif
+            // (as in `stage`: the prefetched fragments of the next tile must have landed before compiler-scheduled code runs)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(flag) :: "memory");
             float sc[16];
             uint64_t m[16];
             if (AUXM == 2) { scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); }
@@ -1505,7 +1514,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 hc0, hc1, hc2, hc3;
+        u32x4 hc0 = {0, 0, 0, 0}, hc1 = hc0, hc2 = hc0, hc3 = hc0;
         for (; t + 1 < ntl; t += 2) {
 #ifdef MS_STAMP
             if (t == (ntl / 4) * 2) { stamp_cm = __builtin_amdgcn_s_memtime(); stamp_rm = __builtin_amdgcn_s_memrealtime(); }
@@ -1513,17 +1522,15 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             // shared bound (ScanHist): every 16th tile this query's 16 bucket counters are fetched (sc1: past this CU's L1)
             // while two tiles are multiplied, then the threshold is raised.  The two tests are evaluated separately on purpose
             // (kept apart by the empty asm): carried from one to the other, hipcc keeps the flag in a vector register.
-            uint32_t hcv[16];            // PF: the same fetch as compiler-visible agent-scope loads (see stage_pf)
-            if (PF && hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
+            // (volatile vector loads, not asm: the insertion path -- compiler-scheduled code -- may run while they are in flight,
+            //  and a register the hardware fills behind the compiler's back is not safe there: with 32-entry lists the
+            //  allocator moved such registers, the counts came out as garbage now and then, and a threshold was raised too
+            //  far -- one query in thousands lost a row.  The compiler waits for these loads where their values are used.)
+            if (hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
-#pragma unroll
-                for (int j = 0; j < 16; ++j) hcv[j] = __hip_atomic_load(hp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (!PF && hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
-                const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
-                asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                             "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
-                             : "=&v"(hc0), "=&v"(hc1), "=&v"(hc2), "=&v"(hc3) : "v"(hp) : "memory");
+                const volatile __attribute__((address_space(1))) u32x4 *hp4 =
+                    (const volatile __attribute__((address_space(1))) u32x4 *)(uintptr_t)hp;
+                hc0 = hp4[0]; hc1 = hp4[1]; hc2 = hp4[2]; hc3 = hp4[3];
             }
             ensure_landed(t);
             run_stage(std::true_type{}, t, acc0, acc1);
@@ -1532,12 +1539,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             asm volatile("" : "+s"(t2));
             if (hist_on && (t2 & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
-                if (!PF) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
-                uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
-                if (PF) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) c[j] = hcv[j];
-                }
+                const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
                 uint32_t cum = 0;
                 int n_lt = 0;
 #pragma unroll

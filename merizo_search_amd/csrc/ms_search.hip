@@ -486,24 +486,35 @@ void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
 // last arriver resets its counter).  They do NOT live in the caller's workspace -- memory the library cannot vouch for
 // between calls (a freed workspace's address may come back holding anything) -- but in a small block the library allocates
 // and zeroes itself, one per (workspace pointer, device): calls that share a workspace are serialised by the caller anyway
-// (they share the partial lists), so they may share the block.  No block left (more than 64 workspaces alive): the search
-// runs with a merge launch instead.
-struct SyncBlock { const void *ws; int dev; char *mem; };
+// (they share the partial lists), so they may share the block.  64 blocks; a 65th workspace takes over the least recently used
+// one (after a device synchronisation: a rare event).
+struct SyncBlock { const void *ws; int dev; char *mem; uint64_t last_use; };
 constexpr int SYNC_BLOCKS = 64;
 constexpr size_t SYNC_BYTES = 512;         // [0,256) 64 arrival counters of the in-launch merge; [256] the prefilter's gate word
 SyncBlock g_sync[SYNC_BLOCKS];
 int g_sync_used = 0;
+uint64_t g_sync_clock = 0;
 char *sync_block_for(const void *ws) {
     std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     for (int i = 0; i < g_sync_used; ++i)
-        if (g_sync[i].ws == ws && g_sync[i].dev == dev) return g_sync[i].mem;
-    if (g_sync_used == SYNC_BLOCKS) return nullptr;
+        if (g_sync[i].ws == ws && g_sync[i].dev == dev) { g_sync[i].last_use = ++g_sync_clock; return g_sync[i].mem; }
+    if (g_sync_used == SYNC_BLOCKS) {
+        // every block is taken: the least recently used one of this device changes hands -- after the device has drained
+        // (launches of its old workspace may still be in flight on another stream) and with its counters zeroed again
+        int lru = -1;
+        for (int i = 0; i < g_sync_used; ++i)
+            if (g_sync[i].dev == dev && (lru < 0 || g_sync[i].last_use < g_sync[lru].last_use)) lru = i;
+        if (lru < 0 || hipDeviceSynchronize() != hipSuccess || hipMemset(g_sync[lru].mem, 0, SYNC_BYTES) != hipSuccess) return nullptr;
+        g_sync[lru].ws = ws;
+        g_sync[lru].last_use = ++g_sync_clock;
+        return g_sync[lru].mem;
+    }
     char *mem = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&mem), SYNC_BYTES) != hipSuccess) return nullptr;
     if (hipMemset(mem, 0, SYNC_BYTES) != hipSuccess) { (void)hipFree(mem); return nullptr; }
-    g_sync[g_sync_used++] = SyncBlock{ws, dev, mem};
+    g_sync[g_sync_used++] = SyncBlock{ws, dev, mem, ++g_sync_clock};
     return mem;
 }
 int inkernel_norm_setting() {      // MS_MODE_IP_NORMQ: up to this many queries are normalised by the scan's own waves (one batch of row loads)

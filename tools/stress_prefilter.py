@@ -1,0 +1,48 @@
+"""Randomised parity sweep of the prefiltered search against the fp32 scan on the GPU (both through the C ABI; the fp32 scan is
+the one pinned to the oracle): larger shapes than the oracle sweep can afford, plain / clustered / rescaled databases.
+usage: python tools/stress_prefilter.py SEED CASES"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from merizo_search_amd import ops
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+bad = fell = 0
+t0 = time.time()
+g = torch.Generator(device="cuda")
+for c in range(ncases):
+    n = int(rng.choice([rng.integers(65_536, 200_000), rng.integers(200_000, 1_000_000), rng.integers(1_000_000, 3_000_000)]))
+    nq = int(rng.choice([rng.integers(65, 129), rng.integers(129, 600), rng.integers(600, 1500)]))
+    k = int(rng.choice([1, 5, 10, 16, 24, 32, 48]))
+    kind = int(rng.integers(0, 4))
+    g.manual_seed(int(rng.integers(0, 1 << 30)))
+    db = torch.randn((n, 128), generator=g, device="cuda")
+    q = torch.randn((nq, 128), generator=g, device="cuda")
+    if kind == 1:        # families: 2,000 centres, every row a centre plus a little noise (many rows within 1e-3 of each other)
+        centres = torch.randn((2000, 128), generator=g, device="cuda")
+        db = centres[torch.randint(0, 2000, (n,), generator=g, device="cuda")] + 0.002 * db
+        q = centres[torch.randint(0, 2000, (nq,), generator=g, device="cuda")] + 0.05 * q
+    if kind == 2:        # exact duplicates of a few queries scattered through the database
+        idx = torch.randint(0, n, (200,), generator=g, device="cuda")
+        db[idx] = q[torch.randint(0, min(nq, 8), (200,), generator=g, device="cuda")]
+    db = db / db.norm(dim=1, keepdim=True)
+    scale = 1.0
+    if kind == 3:        # rows that are not unit vectors
+        db = db * (0.1 + 4.0 * torch.rand((n, 1), generator=g, device="cuda"))
+    bound = float(1.0 / ops.row_inv_norms(db, 1e-30).min()) * (1 + 1e-6)
+    raw = bool(rng.integers(0, 2))
+    mode = ops.MODE_IP_NORMQ if raw else ops.MODE_IP_PRENORM
+    if not raw:
+        q = q / q.norm(dim=1, keepdim=True)
+    off = int(rng.integers(0, 1 << 33))
+    s0, i0 = ops.ip_topk(db, q, k, mode=mode, row_offset=off)
+    ws = ops.PrefilterWorkspace(db.device).get(n, nq, k)
+    s1, i1 = ops.ip_topk_prefiltered(db, q, k, bound, mode=mode, row_offset=off, workspace=ws)
+    fb = ops.prefilter_fell_back(ws)
+    fell += int(fb)
+    if not (torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))):
+        bad += 1
+        print("MISMATCH", dict(n=n, nq=nq, k=k, kind=kind, raw=raw, fell_back=fb))
+    del db, q, ws
+print(f"{ncases} cases, {bad} mismatches, exact pass needed in {fell}, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)

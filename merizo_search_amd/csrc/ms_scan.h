@@ -1174,6 +1174,8 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     };
 
     f32x4 areg[16];
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 hc0 = {0, 0, 0, 0}, hc1 = hc0, hc2 = hc0, hc3 = hc0;      // the shared bound's counters of this lane's query, as last fetched
     const uint32_t lin0 = ring_lds + (uint32_t)(8192 * h + 16 * r);         // fragment f of this lane in slot s: lin0 + 16384 s + 512 f
     uint32_t landed_addr = ring_lds + LDR_R * 16384 + LDR_AUX * 256;
     uint32_t cons_addr = landed_addr + 32 + 4 * wave, two = 2, flag = 0;
@@ -1310,6 +1312,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]),
                              "+v"(areg[6]), "+v"(areg[7]), "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]),
                              "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]), "+v"(flag) :: "memory");
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");     // (a counter fetch may be in flight too)
                 float sc[16];
                 uint64_t m[16];
                 if (AUXM == 2) {            // unit rows: the length mask (dbsearch.py:76,78) is applied here, to the whole tile
@@ -1387,6 +1390,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #endif
             // (as in `stage`: the prefetched fragments of the next tile must have landed before compiler-scheduled code runs)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(flag) :: "memory");
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
             float sc[16];
             uint64_t m[16];
             if (AUXM == 2) { scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); }
@@ -1513,8 +1517,6 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         // every tile, the partial last one included, goes through the pipeline; its rows past
         // row_end are rejected by the filter of the last stage / the drain below
         int t = 0;
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        u32x4 hc0 = {0, 0, 0, 0}, hc1 = hc0, hc2 = hc0, hc3 = hc0;
         for (; t + 1 < ntl; t += 2) {
 #ifdef MS_STAMP
             if (t == (ntl / 4) * 2) { stamp_cm = __builtin_amdgcn_s_memtime(); stamp_rm = __builtin_amdgcn_s_memrealtime(); }
@@ -1522,15 +1524,22 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             // shared bound (ScanHist): every 16th tile this query's 16 bucket counters are fetched (sc1: past this CU's L1)
             // while two tiles are multiplied, then the threshold is raised.  The two tests are evaluated separately on purpose
             // (kept apart by the empty asm): carried from one to the other, hipcc keeps the flag in a vector register.
-            // (volatile vector loads, not asm: the insertion path -- compiler-scheduled code -- may run while they are in flight,
-            //  and a register the hardware fills behind the compiler's back is not safe there: with 32-entry lists the
-            //  allocator moved such registers, the counts came out as garbage now and then, and a threshold was raised too
-            //  far -- one query in thousands lost a row.  The compiler waits for these loads where their values are used.)
+            // (asm: four loads, asynchronous, no wait here.  The insertion path -- compiler-scheduled code -- may run while they are
+            //  in flight, and a register the hardware fills behind the compiler's back is not safe there: it starts with a
+            //  wait for them, see `stage`.  The prefilter's stage is compiler-scheduled throughout and uses atomic loads.)
             if (hist_on && (t & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 const uint32_t *hp = hg.counters != nullptr ? hg.counters : p.hist;
-                const volatile __attribute__((address_space(1))) u32x4 *hp4 =
-                    (const volatile __attribute__((address_space(1))) u32x4 *)(uintptr_t)hp;
-                hc0 = hp4[0]; hc1 = hp4[1]; hc2 = hp4[2]; hc3 = hp4[3];
+                if (PF) {
+                    uint32_t c_[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) c_[j] = __hip_atomic_load(hp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    hc0 = u32x4{c_[0], c_[1], c_[2], c_[3]}; hc1 = u32x4{c_[4], c_[5], c_[6], c_[7]};
+                    hc2 = u32x4{c_[8], c_[9], c_[10], c_[11]}; hc3 = u32x4{c_[12], c_[13], c_[14], c_[15]};
+                } else {
+                    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                                 "global_load_dwordx4 %2, %4, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %4, off offset:48 sc1"
+                                 : "=&v"(hc0), "=&v"(hc1), "=&v"(hc2), "=&v"(hc3) : "v"(hp) : "memory");
+                }
             }
             ensure_landed(t);
             run_stage(std::true_type{}, t, acc0, acc1);
@@ -1539,6 +1548,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             asm volatile("" : "+s"(t2));
             if (hist_on && (t2 & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
+                if (!PF) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
                 const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
                 uint32_t cum = 0;
                 int n_lt = 0;

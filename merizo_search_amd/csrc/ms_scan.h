@@ -1548,7 +1548,15 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             asm volatile("" : "+s"(t2));
             if (hist_on && (t2 & (MS_HIST_PERIOD - 1)) == MS_HIST_PERIOD / 2) {
                 // the highest bucket edge with at least k rows at or above it (counted by all waves so far) bounds the k-th best
-                if (!PF) asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
+                if (!PF) {     // (compiler-scheduled arithmetic follows: the counters and the stage's last fragment reads must have landed)
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
+                    if constexpr (RING_FRAGS)
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(flag) :: "memory");
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(areg[4]), "+v"(areg[5]),
+                                     "+v"(areg[6]), "+v"(areg[7]), "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]),
+                                     "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]), "+v"(flag) :: "memory");
+                }
                 const uint32_t c[16] = {hc0.x, hc0.y, hc0.z, hc0.w, hc1.x, hc1.y, hc1.z, hc1.w, hc2.x, hc2.y, hc2.z, hc2.w, hc3.x, hc3.y, hc3.z, hc3.w};
                 uint32_t cum = 0;
                 int n_lt = 0;

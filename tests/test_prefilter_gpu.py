@@ -188,3 +188,18 @@ def test_engine_switches_the_prefilter_off_after_two_batches_that_needed_the_exa
         s.cpu()
         e.prefilter_feedback()
         assert e._pf_enabled == (call < 1)
+
+
+@pytest.mark.parametrize("k", [10, 40])
+def test_prefiltered_repeated_searches_return_identical_results(k, torch_gpu):
+    """Run-to-run determinism of the prefiltered search (100 runs of one search; the first against the fp32 scan)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    n, nq = 202_000, 738
+    d, dq = _dev(torch, _norm_db(n, seed=46)), _dev(torch, _norm_db(nq, seed=47))
+    ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    s_ref, i_ref = ops.ip_topk(d, dq, k)
+    for _ in range(100):
+        s, i = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, workspace=ws)
+        assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32))
+    assert not ops.prefilter_fell_back(ws)

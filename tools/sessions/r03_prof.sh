@@ -14,23 +14,23 @@ kt() { name=$1; shift; timeout 900 rocprofv3 --kernel-trace --stats --output-for
 pmc() { name=$1; ctr=$2; shift; shift; timeout 900 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_${name} -o pmc -- python3 "$@" > $OUT/pmc_${name}.log 2>&1; echo "pmc $name rc=$?"; }
 tojson() { python3 $R/tools/pmc_to_json.py "$@" > /dev/null; }
 # C2 headline: the default bench step
-kt c2 $R/bench.py --no-extras --no-cpu-baseline
-pmc c2_fetch FETCH_SIZE $R/bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 3
-pmc c2_write WRITE_SIZE $R/bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 3
-pmc c2_busy "$BUSY" $R/bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 3
-tojson $OUT/r03_c2_pmc.json "ms_scan_loader_kernel<5, 0, false>" "bench.py --no-extras --no-cpu-baseline --steps 5 --warmup 3 (C2: 1,000,000 x 128 rows, 256 queries, top-10)" 512000000 65536000000 /tmp/pmc_c2_fetch /tmp/pmc_c2_write /tmp/pmc_c2_busy
+kt c2 $R/bench.py --no-extras --no-cpu-baseline --no-prefilter
+pmc c2_fetch FETCH_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
+pmc c2_write WRITE_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
+pmc c2_busy "$BUSY" $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
+tojson $OUT/r03_c2_pmc.json "ms_scan_loader_kernel<5, 0, false, false>" "bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3 (C2: 1,000,000 x 128 rows, 256 queries, top-10)" 512000000 65536000000 /tmp/pmc_c2_fetch /tmp/pmc_c2_write /tmp/pmc_c2_busy
 # one rank's share of C4
 kt c4 $R/tools/prof_scan.py 45625000 4096 10 2
 pmc c4_busy "$BUSY" $R/tools/prof_scan.py 45625000 4096 10 1
 pmc c4_fetch FETCH_SIZE $R/tools/prof_scan.py 45625000 4096 10 1
 pmc c4_write WRITE_SIZE $R/tools/prof_scan.py 45625000 4096 10 1
-tojson $OUT/r03_c4_pmc.json "ms_scan_loader_kernel<5, 0, false>" "tools/prof_scan.py 45625000 4096 10 1 (one rank's share of C4)" 23360000000 47841280000000 /tmp/pmc_c4_fetch /tmp/pmc_c4_write /tmp/pmc_c4_busy
+tojson $OUT/r03_c4_pmc.json "ms_scan_loader_kernel<5, 0, false, false>" "tools/prof_scan.py 45625000 4096 10 1 (one rank's share of C4)" 23360000000 47841280000000 /tmp/pmc_c4_fetch /tmp/pmc_c4_write /tmp/pmc_c4_busy
 # c3_search: cosine + length mask on unit rows
 kt c3 $R/tools/prof_c3.py 20
 pmc c3_busy "$BUSY" $R/tools/prof_c3.py 5
 pmc c3_fetch FETCH_SIZE $R/tools/prof_c3.py 5
 pmc c3_write WRITE_SIZE $R/tools/prof_c3.py 5
-tojson $OUT/r03_c3_pmc.json "ms_scan_loader_kernel<5, 2, false>" "tools/prof_c3.py 5 (c3_search: 500,000 unit rows + lengths, 1000 queries, mincov 0.7, top-10)" 258000000 128000000000 /tmp/pmc_c3_fetch /tmp/pmc_c3_write /tmp/pmc_c3_busy
+tojson $OUT/r03_c3_pmc.json "ms_scan_loader_kernel<5, 2, false, false>" "tools/prof_c3.py 5 (c3_search: 500,000 unit rows + lengths, 1000 queries, mincov 0.7, top-10)" 258000000 128000000000 /tmp/pmc_c3_fetch /tmp/pmc_c3_write /tmp/pmc_c3_busy
 # HBM-bound regime (one call per search)
 for shape in "1000000 1" "1000000 32" "4000000 1" "4000000 32" "45625000 1" "45625000 32"; do set -- $shape
   kt hbm_$1_$2 $R/tools/hbm_shape.py $1 $2 40

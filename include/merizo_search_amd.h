@@ -102,37 +102,53 @@ int ms_ip_topk_scan(const float *db, int64_t n, const float *q, int nq, int k, i
 int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_scores, int64_t *out_idx,
                       void *workspace, size_t workspace_bytes, ms_stream_t stream);
 
-/* The same search as ms_ip_topk in the inner-product modes (MS_MODE_IP_PRENORM / MS_MODE_IP_NORMQ) -- index.search of
- * dbsearch.py:234-242 -- with the SAME results bit for bit, several times faster for batches of more than 64 queries and
- * k <= 32.  The rows are scanned once with bf16 matrix instructions on operands split in registers (hi + lo halves of every
- * float: no second copy of the database, no other layout), which gives every score to within 2.5e-4 |row| |q|; the 2k-4k
- * best rows per query by that score are re-scored with the exact fp32 chain and the best k of them are returned -- after a
- * per-query proof that no other row can belong to the answer (the k-th exact score exceeds the last kept approximate score
- * by more than the error bound).  Where the proof fails (dozens of rows within the error bound of the k-th best), the
- * exact fp32 pipeline, queued behind on the same stream, runs for the batch: always exact, never an approximation.
- *   row_norm_bound   an upper bound on the L2 norm of every row of db (1.0 for a database of unit vectors, as
- *                    dbfname_IP holds; 1 / min(ms_row_inv_norms) otherwise); <= 0, not finite (a database with non-finite
- *                    rows has no bound) or shapes outside the above: the call is ms_ip_topk.  Queries with non-finite
- *                    elements fail their proof and get the exact pass.
+/* ---- the prefiltered search: the same results as ms_ip_topk bit for bit, several times faster for large batches ----
+ *
+ * Replaces index.search of dbsearch.py:234-242 (MS_MODE_IP_PRENORM / MS_MODE_IP_NORMQ) and, on rows normalised once,
+ * search_query_against_db of dbsearch.py:75-81 (MS_MODE_COSINE_UNIT) for batches of more than 64 queries, k <= MS_PREFILTER_MAX_K and
+ * databases of >= 65,536 rows.  The rows are scanned once with bf16 matrix instructions on split operands (hi + lo halves of
+ * every float), which gives every score to within 2.5e-4 |row| |q|; the 2k-4k best rows per query by that score are re-scored
+ * with the exact fp32 chain (ms_ip_topk's own arithmetic, from the fp32 rows) and the best k of them are returned -- after a
+ * PER-QUERY proof that no other row can belong to the answer (the k-th exact score exceeds the last kept approximate score by
+ * more than the error bound).  Queries whose proof fails (dozens of rows within the error bound of their k-th best: families of
+ * near-duplicates) are gathered into a dense batch on the device and an exact fp32 scan, queued behind on the same stream, runs
+ * for THOSE queries only: always exact, never an approximation, and a clustered query costs only itself.
+ *
+ *   pf_image         the split image of db: ms_pf_build_image, made once when the database becomes resident (512 B per row next to
+ *                    the fp32 rows, which stay: the re-scoring and the exact pass read them).  The scan then streams MFMA-ready
+ *                    operands and converts nothing.  NULL: the rows are split in registers instead (no second copy of anything;
+ *                    about 2.5x slower; inner-product modes only -- MS_MODE_COSINE_UNIT without an image is ms_ip_topk).
+ *   lengths / qlen / mincov   MS_MODE_COSINE_UNIT: the length mask of dbsearch.py:76 (NULL, NULL: none); NULL in the other modes.
+ *   row_norm_bound   an upper bound on the L2 norm of every row of db (1.0 + 1e-6 for unit rows, as dbfname_IP and
+ *                    MS_MODE_COSINE_UNIT hold; 1 / min(ms_row_inv_norms) otherwise); <= 0, not finite (a database with non-finite
+ *                    rows has no bound) or shapes outside the above: the call is ms_ip_topk.  Queries with non-finite elements
+ *                    fail their proof and get the exact pass.
  * Workspace: ms_ip_topk_prefiltered_workspace_bytes.  _prepare / _scan / _finish: its three stages as for ms_ip_topk
- * (queries + sample pass; the one scan launch; merge + exact re-scoring + the gated exact pipeline). */
+ * (queries + sample pass; the one scan launch; merge + exact re-scoring + the exact pass over the flagged queries). */
+#define MS_PREFILTER_MAX_K 48
+size_t ms_pf_image_bytes(int64_t n);
+int ms_pf_build_image(const float *db, int64_t n, void *pf_image, ms_stream_t stream);
 size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k);
-int ms_ip_topk_prefiltered(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
-                           float row_norm_bound, float *out_scores, int64_t *out_idx, void *workspace,
-                           size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound,
-                                   void *workspace, size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound,
-                                void *workspace, size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_finish(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
-                                  float row_norm_bound, float *out_scores, int64_t *out_idx, void *workspace,
-                                  size_t workspace_bytes, ms_stream_t stream);
-/* Diagnostics (tests): synchronises the device; *gate_value == *last_epoch means the last prefiltered search on this
- * workspace needed the exact pipeline. */
-int ms_debug_prefilter_gate(void *workspace, unsigned int *gate_value, unsigned int *last_epoch);
+int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k,
+                           int mode, const float *lengths, const float *qlen, float mincov, float row_norm_bound,
+                           float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+                                   const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
+                                   size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+                                const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
+                                size_t workspace_bytes, ms_stream_t stream);
+int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq,
+                                  int k, int mode, const float *lengths, const float *qlen, float mincov, float row_norm_bound,
+                                  float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes,
+                                  ms_stream_t stream);
+/* Diagnostics (tests; synchronises the device): what the last prefiltered search on this workspace left behind -- *flagged =
+ * how many of its queries needed the exact pass (0: every answer was proved), *gate_value == *last_epoch iff any did. */
+int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned int *last_epoch, unsigned int *flagged);
 /* Diagnostics (tools/pf_debug.py): the candidate lists of the last prefiltered search on this workspace, copied to the host
- * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); -1 when the shape is not served by the prefilter. */
-int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, float *as_host, int64_t *ai_host, int *kp_out);
+ * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); image: was it a search over a split image; -1 when the shape is
+ * not served by the prefilter. */
+int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, int image, float *as_host, int64_t *ai_host, int *kp_out);
 
 /* Merge S sorted result lists per query into the best k: faiss.ResultHeap(nq,k).add_result /
  * finalize (dbsearch.py:224,240,245) and the cross-shard merge after the RCCL all-gather.

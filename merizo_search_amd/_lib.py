@@ -19,6 +19,8 @@ MODE_COSINE_RAW = 1
 MODE_COSINE_UNIT = 2
 MODE_IP_NORMQ = 3
 DIM = 128
+PREFILTER_MAX_K = 48       # MS_PREFILTER_MAX_K (include/merizo_search_amd.h): the prefiltered search serves k up to this
+PREFILTER_MIN_ROWS = 65536
 
 
 class MerizoHipError(RuntimeError):
@@ -47,13 +49,15 @@ SIGNATURES = {
     "ms_ip_topk_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
+    "ms_pf_image_bytes": (_sz, [_i64]),
+    "ms_pf_build_image": (_int, [_vp, _i64, _vp, _vp]),
     "ms_ip_topk_prefiltered_workspace_bytes": (_sz, [_i64, _int, _int]),
-    "ms_ip_topk_prefiltered": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _f, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _f, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_finish": (_int, [_vp, _i64, _i64, _vp, _int, _int, _int, _f, _vp, _vp, _vp, _sz, _vp]),
-    "ms_debug_prefilter_gate": (_int, [_vp, _vp, _vp]),
-    "ms_debug_prefilter_lists": (_int, [_vp, _i64, _int, _int, _vp, _vp, _vp]),
+    "ms_ip_topk_prefiltered": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_prepare": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_scan": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_finish": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_debug_prefilter_state": (_int, [_vp, _vp, _vp, _vp]),
+    "ms_debug_prefilter_lists": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge_strided": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_egnn_weight_floats": (_sz, []),

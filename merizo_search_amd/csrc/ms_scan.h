@@ -9,6 +9,34 @@
 #include <type_traits>
 
 // ------------------------------------------------------------------ scan kernel --------
+// The decomposition of one scan launch: query tiles x row streams.  Computed on the host for an ordinary search (make_plan) and ON
+// THE DEVICE for the exact pass behind a prefiltered search, whose batch -- the queries whose proof failed -- is only known there
+// (ms_compact_flagged_kernel writes a ScanDevPlan, the gated scan and merge read it).
+struct ScanDevPlan {
+    int nq, nq_pad, n_qtiles, qwb, n_qgroups, n_sgroups, n_streams, rows_per_stream, P, grid;
+    int pad_[6];
+};
+__host__ __device__ inline void ms_plan_core(int64_t n, int nq, int cus, ScanDevPlan *d) {
+    d->nq = nq;
+    d->n_qtiles = (nq + 31) / 32;
+    d->qwb = d->n_qtiles >= 3 ? 4 : (d->n_qtiles == 2 ? 2 : 1);
+    d->n_qgroups = (d->n_qtiles + d->qwb - 1) / d->qwb;
+    d->nq_pad = d->n_qgroups * d->qwb * 32;
+    const int64_t tiles = (n + 31) / 32;
+    // one wave per (query tile, stream): one wave on each of the 4 * cus SIMDs
+    int64_t want = ((int64_t)4 * cus) / ((int64_t)d->n_qgroups * d->qwb);
+    if (want < 1) want = 1;
+    if (want > tiles) want = tiles > 0 ? tiles : 1;
+    const int64_t tiles_per_stream = (tiles + want - 1) / want;
+    d->rows_per_stream = (int)((tiles_per_stream > 0 ? tiles_per_stream : 1) * 32);
+    d->n_streams = (int)((n + d->rows_per_stream - 1) / d->rows_per_stream);
+    if (d->n_streams < 1) d->n_streams = 1;
+    const int spb = 4 / d->qwb;
+    d->n_sgroups = (d->n_streams + spb - 1) / spb;
+    d->P = d->qwb == 4 ? d->n_streams : d->n_sgroups;
+    d->grid = ((d->n_sgroups + 7) / 8) * 8 * d->n_qgroups;
+}
+
 struct ScanParams {
     const float *db;        // [n,128]
     int64_t n;
@@ -37,6 +65,10 @@ struct ScanParams {
     int fin_stride;
     int prefilter = 0;      // loader-wave form only: score with three bf16 matrix instructions on the split operands (approximate scores;
                             // the caller re-scores the survivors exactly: ms_ip_topk_prefiltered)
+    const ScanDevPlan *dev_plan = nullptr;   // ms_scan_kernel only: nq, the streams and the grid come from device memory (exact pass
+                                             // over the flagged queries of a prefiltered search); workgroups past its grid return at once
+    const void *pf_image = nullptr;   // prefilter, ms_scan_pf.h: the split-bf16 image of db (ms_pf_build_image), or NULL (split in registers)
+    int qpw = 1;                      // ... and the waves per workgroup of that kernel, one query tile each, in fours (1: 4 waves, 2: 8)
     const uint32_t *gate = nullptr;   // NULL, or: the launch does nothing unless *gate == gate_epoch (the exact pipeline behind a
     uint32_t gate_epoch = 0;          // prefiltered search runs only when the prefilter could not prove its answer)
     uint32_t *ticket;       // [n_qgroups] arrival counters in library-owned memory, zero between launches (the last arriver resets its counter)
@@ -256,15 +288,49 @@ __device__ __forceinline__ void ms_row_insert(ScanState<KL> &st, float v, uint32
     st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
 }
 
+// The same step with a candidate (v, row) of ITS OWN per lane (the split-image prefilter scan empties its per-lane candidate
+// buffers with it): lanes of half hh contribute, every query at most one candidate per call.  Candidates arrive in no particular
+// row order, so entries that tie in score keep no particular order either -- fine for approximate scores, which the exact
+// re-scoring re-ranks (ms_rescore_kernel), not for the fp32 scan.
+template <int KL>
+__device__ __forceinline__ void ms_lane_insert(ScanState<KL> &st, float v, uint32_t row, int hh, int h) {
+    const bool mine = (h == hh) && (v > st.tau);
+    const float c = mine ? v : -INFINITY;
+    const float pc = ms_xor32_f(c, h);
+    const uint32_t prow = ms_xor32_u(row, h);
+    const float cand = (h == hh) ? c : pc;
+    const uint32_t crow = (h == hh) ? row : prow;
+    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+    const bool spill = (h == 1) && (cand > pl_s);
+    const float x_cmp = spill ? __builtin_nanf("") : cand;
+    const float ins_s = spill ? pl_s : cand;
+    const uint32_t ins_i = spill ? pl_i : crow;
+    bool ge_hi = st.ls[KL - 1] >= x_cmp;
+#pragma unroll
+    for (int e = KL - 1; e >= 1; --e) {
+        const bool ge_lo = st.ls[e - 1] >= x_cmp;
+        const float ns = ge_lo ? ins_s : st.ls[e - 1];
+        const uint32_t ni = ge_lo ? ins_i : st.li[e - 1];
+        st.ls[e] = ge_hi ? st.ls[e] : ns;
+        st.li[e] = ge_hi ? st.li[e] : ni;
+        ge_hi = ge_lo;
+    }
+    st.ls[0] = ge_hi ? st.ls[0] : ins_s;
+    st.li[0] = ge_hi ? st.li[0] : ins_i;
+    const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+}
+
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]; rows in ascending
 // order: row 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 #ifndef MS_STATIC_INSERT_MAX_KL
 #define MS_STATIC_INSERT_MAX_KL 32
 #endif
-template <int KL, bool HIST = false>
+template <int KL, bool HIST = false, bool LOOP = false>      // LOOP: the runtime-loop form whatever the list length (small code)
 __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&sc)[16], const uint64_t (&m)[16],
                                                int64_t sub_row0, int r, int h, const ScanHist *hg = nullptr) {
-    if (KL <= (HIST ? 16 : MS_STATIC_INSERT_MAX_KL)) {
+    if (!LOOP && KL <= (HIST ? 16 : MS_STATIC_INSERT_MAX_KL)) {
         // short lists (k <= 10, the common case): one static copy of the step per row
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -305,9 +371,16 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
 }
 
 template <int KL, bool AUX, bool UB, bool MAXONLY>
-__device__ __forceinline__ void ms_scan_body(const ScanParams &p) {
+__device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
+    if (p_in.gate != nullptr && *p_in.gate != p_in.gate_epoch) return;          // (uniform: a scalar load)
+    ScanParams p = p_in;
+    if (p_in.dev_plan != nullptr) {                                     // (uniform: scalar loads)
+        const ScanDevPlan d = *p_in.dev_plan;
+        if ((int)blockIdx.x >= d.grid) return;
+        p.nq = d.nq; p.nq_pad = d.nq_pad; p.n_qtiles = d.n_qtiles; p.qwb = d.qwb; p.n_qgroups = d.n_qgroups; p.n_sgroups = d.n_sgroups;
+        p.n_streams = d.n_streams; p.rows_per_stream = d.rows_per_stream; p.P = d.P;
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     // the wave index is uniform across the wave: say so, or every row / stream / loop quantity
     // below becomes 64-bit per-lane arithmetic
@@ -887,6 +960,10 @@ constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
 template <int IMM>
 __device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
+}
+template <int IMM>      // the same with sc1: past this CU's L1 (counters other workgroups are adding to)
+__device__ __forceinline__ void ms_glds_s16_sc1(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 sc1" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
 }
 __device__ __forceinline__ void ms_glds_v4(uint32_t lds_addr, const void *lane_ptr) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(lds_addr), "v"(lane_ptr) : "memory", "m0");
@@ -1646,6 +1723,7 @@ struct ScanPlan {
     int rows_per_stream, n_streams, n_sgroups, P;
     int grid;
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
+    int qpw;               // split-image prefilter scan (ms_scan_pf.h): query tiles per wave (0: any other kernel)
     size_t lds_bytes;
     // workspace carve (byte offsets)
     size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, total;

@@ -92,6 +92,7 @@ __global__ __launch_bounds__(256) void ms_prepare_queries_kernel(const float *q,
 }
 
 #include "ms_scan.h"
+#include "ms_scan_pf.h"
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -209,12 +210,21 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 // or above it rank themselves; no serial rounds).  The form launch_merge uses for P <= 256 lists when the [k][P] block
 // fits in LDS; shapes ms_block_merge declines (fewer lists than k, ties by the hundred) go through the head-advance merge of
 // the workgroup's first wave.
+// dp / qmap (the exact pass over the flagged queries of a prefiltered search): the number of queries and of lists comes from the
+// device plan, and query q of the compacted batch is row qmap[q] of the outputs.
 __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
-                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
+                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
+                                                             const ScanDevPlan *dp, const int *qmap) {
     if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int q = blockIdx.x, tid = threadIdx.x, kP = k * P;
+    int q = blockIdx.x;
+    if (dp != nullptr) {
+        if (q >= dp->nq) return;
+        P = dp->P;
+    }
+    const int q_out = qmap != nullptr ? qmap[q] : q;
+    const int tid = threadIdx.x, kP = k * P;
     uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
     const size_t base = (size_t)q * kP;
     if ((kP & 3) == 0) {
@@ -235,16 +245,16 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
     __syncthreads();
     const uint2 *fin = ms_block_merge(ent, smem, P, k, tid);
     if (fin == nullptr) {        // (uniform across the workgroup)
-        if (tid < 64)
-            ms_head_merge_wave<4, true>(ent, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, q, tid);
+        if (tid < 64)       // (`ent` is staged already: the wave reads nothing at part_s / part_i, and q only names the output row)
+            ms_head_merge_wave<4, true>(ent, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, q_out, tid);
         return;
     }
     if (tid < k) {
         const uint2 v = fin[tid];
-        const size_t o = (size_t)q * out_stride + out_col0 + tid;
+        const size_t o = (size_t)q_out * out_stride + out_col0 + tid;
         out_s[o] = __uint_as_float(v.x);
         out_i[o] = v.y == MS_IDX_NONE ? (int64_t)-1 : row_offset + (int64_t)v.y;
-        if (tid == k - 1 && ub_s != nullptr) { ub_s[q] = __uint_as_float(v.x); ub_i[q] = v.y; }
+        if (tid == k - 1 && ub_s != nullptr) { ub_s[q_out] = __uint_as_float(v.x); ub_i[q_out] = v.y; }
     }
 }
 
@@ -309,8 +319,9 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 // answer or tie with it (the candidate list must be full for that argument: a list with empty slots raises the gate too).  Otherwise (near-ties by the dozen around the k-th best) the query raises the gate and the exact
 // pipeline, queued behind this kernel, runs after all.
 __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
-                                                        const int64_t *ai, int64_t row_offset, float err_coef, float *out_s,
-                                                        int64_t *out_i, uint32_t *gate, uint32_t epoch, float *exact_lb) {
+                                                        const int64_t *ai, int64_t row_offset, float err_coef, const float *lengths,
+                                                        const float *qlen, float mincov, float *out_s, int64_t *out_i, uint32_t *flag,
+                                                        float *exact_lb) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -340,6 +351,12 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
             acc = fmaf(lo.w, qs[4 * t + 3], acc); acc = fmaf(hi.w, qs[64 + 4 * t + 3], acc);
         }
         s = acc;
+        if (lengths != nullptr) {       // MS_MODE_COSINE_UNIT: the fp32 scan's own two multiplications (unit rows: scale 1; dbsearch.py:76,78)
+            float sv = s * 1.0f;
+            const float mk = (qlen[q] >= lengths[row] * mincov) ? 1.0f : 0.0f;
+            sv = sv * mk;
+            s = sv;
+        }
     }
     cs[lane] = s;
     ci[lane] = row >= 0 ? (uint32_t)row : MS_IDX_NONE;
@@ -355,7 +372,54 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     if (lane == 0) {
         exact_lb[q] = kth;      // k rows score at least this: the bound the exact scan starts from, should it have to run (-inf: none)
         // (a list that is not full cannot happen on a database of >= 65,536 rows unless rows were lost to a bound: no proof then either)
-        if (!full || !(kth > a_last + err_coef * qnorm)) atomicMax(gate, epoch);
+        flag[q] = (!full || !(kth > a_last + err_coef * qnorm)) ? 1u : 0u;
+    }
+}
+
+// The queries whose proof failed, gathered into a dense batch for the exact pass: their prepared query vectors, their lower
+// bounds (the k-th best exact score among their candidates) and query lengths, the map back to their rows of the outputs, and
+// the launch decomposition of an exact scan over exactly that many queries (ms_plan_core, the host's own arithmetic).  One
+// workgroup; the gate word is set to this call's epoch when there is anything to do (the gated launches return at once otherwise).
+__global__ __launch_bounds__(256) void ms_compact_flagged_kernel(const uint32_t *flag, int nq, int64_t n, int cus, const float *qn,
+                                                                 const float *exact_lb, const float *qlen, float *qn_c, float *lb_c,
+                                                                 float *qlen_c, int *qmap, ScanDevPlan *dp, uint32_t *gate, uint32_t epoch) {
+    __shared__ int wave_cnt[4];
+    __shared__ int base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int q = q0 + tid;
+        const bool f = q < nq && flag[q] != 0u;
+        const unsigned long long bal = __ballot(f);
+        const int before = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (f) {
+            const int j = off + before;
+            qmap[j] = q;
+            lb_c[j] = exact_lb[q];
+            qlen_c[j] = qlen != nullptr ? qlen[q] : 0.0f;
+        }
+        __syncthreads();
+        if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
+        __syncthreads();
+    }
+    const int cnt = base;
+    for (int e = tid; e < cnt * (MS_DIM / 4); e += 256) {
+        const int j = e / (MS_DIM / 4), c = e % (MS_DIM / 4);
+        reinterpret_cast<float4 *>(qn_c)[(size_t)j * (MS_DIM / 4) + c] = reinterpret_cast<const float4 *>(qn)[(size_t)qmap[j] * (MS_DIM / 4) + c];
+    }
+    if (tid == 0) {
+        ScanDevPlan d;
+        ms_plan_core(n, cnt > 0 ? cnt : 1, cus, &d);
+        if (cnt == 0) { d.nq = 0; d.grid = 0; }
+        *dp = d;
+        gate[0] = cnt > 0 ? epoch : 0u;
+        gate[1] = epoch;                 // (diagnostics: the epoch of the last prefiltered search on this workspace, and how many
+        gate[2] = (uint32_t)cnt;         //  of its queries needed the exact pass)
     }
 }
 
@@ -552,29 +616,38 @@ int pick_kl(int k_pass) {
     return 32;
 }
 
-ScanPlan make_plan(int64_t n, int nq, int k, int cus) {
+// qpw > 0: the plan of the split-image prefilter scan (ms_scan_pf.h): 4 waves x qpw query tiles per workgroup, one workgroup per CU
+ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
     ScanPlan pl;
-    pl.n_qtiles = (nq + 31) / 32;
     pl.nq_real = nq;
-    pl.qwb = pl.n_qtiles >= 3 ? 4 : (pl.n_qtiles == 2 ? 2 : 1);
-    pl.n_qgroups = (pl.n_qtiles + pl.qwb - 1) / pl.qwb;
-    pl.nq_pad = pl.n_qgroups * pl.qwb * 32;
+    pl.qpw = qpw;
     pl.k_pass = k < 64 ? k : 64;
     pl.kl = pick_kl(pl.k_pass);
-    const int waves_per_simd = 1;   // the scan is software-pipelined inside each wave
     const int64_t tiles = (n + 31) / 32;
-    // one wave per (query tile, stream): aim at waves_per_simd waves on each of the 4*cus SIMDs
-    int64_t want = ((int64_t)waves_per_simd * 4 * cus) / ((int64_t)pl.n_qgroups * pl.qwb);
-    if (want < 1) want = 1;
-    if (want > tiles) want = tiles > 0 ? tiles : 1;
-    const int64_t tiles_per_stream = (tiles + want - 1) / want;
-    pl.rows_per_stream = (int)((tiles_per_stream > 0 ? tiles_per_stream : 1) * 32);
-    pl.n_streams = (int)((n + pl.rows_per_stream - 1) / pl.rows_per_stream);
-    if (pl.n_streams < 1) pl.n_streams = 1;
-    const int spb = 4 / pl.qwb;
-    pl.n_sgroups = (pl.n_streams + spb - 1) / spb;
-    pl.P = pl.qwb == 4 ? pl.n_streams : pl.n_sgroups;
-    pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
+    int64_t tiles_per_stream;
+    if (qpw == 0) {
+        ScanDevPlan d;
+        ms_plan_core(n, nq, cus, &d);      // (the same arithmetic the device runs for the exact pass behind a prefiltered search)
+        pl.n_qtiles = d.n_qtiles; pl.qwb = d.qwb; pl.n_qgroups = d.n_qgroups; pl.nq_pad = d.nq_pad; pl.rows_per_stream = d.rows_per_stream;
+        pl.n_streams = d.n_streams; pl.n_sgroups = d.n_sgroups; pl.P = d.P; pl.grid = d.grid;
+        tiles_per_stream = d.rows_per_stream / 32;
+    } else {
+        pl.n_qtiles = (nq + 31) / 32;
+        pl.qwb = 4;                        // (one list per (stream, query), as in the loader-wave form)
+        const int group_tiles = 4 * qpw;   // query tiles per workgroup
+        pl.n_qgroups = (pl.n_qtiles + group_tiles - 1) / group_tiles;
+        pl.nq_pad = pl.n_qgroups * group_tiles * 32;
+        int64_t want = (int64_t)cus / pl.n_qgroups;
+        if (want < 1) want = 1;
+        if (want > tiles) want = tiles > 0 ? tiles : 1;
+        tiles_per_stream = (tiles + want - 1) / want;
+        pl.rows_per_stream = (int)((tiles_per_stream > 0 ? tiles_per_stream : 1) * 32);
+        pl.n_streams = (int)((n + pl.rows_per_stream - 1) / pl.rows_per_stream);
+        if (pl.n_streams < 1) pl.n_streams = 1;
+        pl.n_sgroups = pl.n_streams;
+        pl.P = pl.n_streams;
+        pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
+    }
     pl.lds_bytes = 4 * 32768 + 4 * 1024;        // tile slots, cosine side data, in-launch bound
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
@@ -626,6 +699,12 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
 }
 
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    if (sp.prefilter && sp.pf_image != nullptr) {                  // the prefilter's scan over the split image
+        if (pick_kl(sp.k) == 5) return ms_launch_scan_pf2_kl5(pl, sp, st);
+        if (pick_kl(sp.k) == 10) return ms_launch_scan_pf2_kl10(pl, sp, st);
+        if (pick_kl(sp.k) == 16) return ms_launch_scan_pf2_kl16(pl, sp, st);
+        return ms_launch_scan_pf2_kl32(pl, sp, st);
+    }
     if (sp.ub_s != nullptr) return ms_launch_scan_kl32ub(pl, sp, st);
     if (pick_kl(sp.k) == 5) return ms_launch_scan_kl5(pl, sp, st);
     if (pick_kl(sp.k) == 10) return ms_launch_scan_kl10(pl, sp, st);
@@ -633,22 +712,26 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     return ms_launch_scan_kl32(pl, sp, st);
 }
 
+// dp / qmap: the merge behind the exact pass over a prefiltered search's flagged queries -- the list count comes from the device
+// plan (pl.P is then its upper bound), query q of the compacted batch is output row qmap[q]
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
-                 int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st) {
+                 int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st,
+                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr) {
     const uint32_t *gate = sp.gate;
     const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
     const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
-    if (block_lds <= 156 * 1024 && pl.P <= 256 && block_merge_setting()) {     // the usual case: a workgroup per query
+    if (block_lds <= 156 * 1024 && pl.P <= 256 && (block_merge_setting() || dp != nullptr)) {     // the usual case: a workgroup per query
         if (block_lds > 48 * 1024)
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
+    if (dp != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the exact pass behind the prefilter needs the block merge (P = %d, k = %d)", pl.P, kp);
     if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
@@ -714,7 +797,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
     sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
-    sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0;
+    sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0; sp->pf_image = nullptr; sp->qpw = pl.qpw;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -732,7 +815,8 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     ScanParams s0 = *sp;
     s0.max_tiles = pl.prepass_tiles;
     s0.lb_s = nullptr;
-    int rc = (pl.qwb == 4 && loader_wave_setting()) ? ms_launch_sample_loader(pl, s0, st) : launch_scan(pl, s0, st);
+    int rc = (s0.prefilter && s0.pf_image != nullptr) ? ms_launch_sample_pf2(pl, s0, st)
+             : ((pl.qwb == 4 && loader_wave_setting()) ? ms_launch_sample_loader(pl, s0, st) : launch_scan(pl, s0, st));
     if (rc) return rc;
     float *lb = reinterpret_cast<float *>(ws + pl.off_lb_s);
     // the sample kernel leaves at most 2 entries per (query, stream) and merges the 4 / qwb streams of a workgroup: only the
@@ -945,66 +1029,99 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
     return MS_OK;
 }
 
-// ---- prefiltered search (inner-product modes, >= 3 query tiles, k <= 32) ----------------------------------------------
-// stages: 1 = queries + sample pass + bound, 2 = the scan launch, 4 = merge + exact re-scoring + the gated exact pipeline
+// ---- prefiltered search (>= 3 query tiles, k <= 48) -------------------------------------------------------------------
+// stages: 1 = queries + sample pass + bound, 2 = the scan launch, 4 = merge + exact re-scoring + the exact pass over the queries
+// whose proof failed
 namespace {
 // candidates kept per query: twice k for short lists, at least 8-16 spare entries for long ones (the proof needs the rows within the
-// error bound of the k-th best to fit; more spare entries = fewer runs of the exact pipeline on clustered data)
-int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 24 ? 32 : (k <= 48 ? 64 : 0))); }
+// error bound of the k-th best to fit; more spare entries = fewer queries for the exact pass on clustered data)
+int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 24 ? 32 : (k <= MS_PREFILTER_MAX_K ? 64 : 0))); }
 int prefilter_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_PREFILTER"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the fp32 scan
     return v;
 }
-std::atomic<uint32_t> g_pf_last_epoch{0};             // epoch of the last prefiltered search (diagnostics)
 uint32_t next_epoch() {                                // never 0: the gate word starts at zero
     static std::atomic<uint32_t> e{1};
     uint32_t v = e.fetch_add(1);
     if (v == 0) v = e.fetch_add(1);
     return v;
 }
-struct PfLayout { ScanPlan pf, exact; size_t off_as, off_ai, total; int kp; bool ok; };
-PfLayout pf_layout(int64_t n, int nq, int k, int mode) {
+// Workspace of a prefiltered search: [the larger of the prefilter scan's and the exact scan's plans | candidate lists (approximate
+// scores, rows) | per-query flags | the compacted batch of the exact pass: queries, bounds, lengths, map | its device plan]
+struct PfLayout {
+    ScanPlan pf, exact;
+    size_t off_as, off_ai, off_flag, off_qn_c, off_lb_c, off_qlen_c, off_qmap, off_dp, off_xs, off_xi, total;
+    int kp, exact_grid_max, exact_P_max;
+    bool ok;
+};
+PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image) {
     PfLayout L;
+    const int cus = cu_count_cached();
     L.kp = pf_list_len(k);
-    L.exact = make_plan(n, nq, k, cu_count_cached());
-    L.ok = prefilter_setting() && L.kp > 0 && (mode == MS_MODE_IP_PRENORM || mode == MS_MODE_IP_NORMQ) && n >= 65536 && L.exact.qwb == 4 &&
-           loader_wave_setting() != 0;
-    if (!L.ok) { L.total = L.exact.total; L.off_as = L.off_ai = 0; return L; }
-    L.pf = make_plan(n, nq, L.kp, cu_count_cached());
+    L.exact = make_plan(n, nq, k, cus);
+    const bool ip = mode == MS_MODE_IP_PRENORM || mode == MS_MODE_IP_NORMQ;
+    // without an image the rows are split in registers (round 3's kernel: inner-product modes only, the loader-wave form)
+    L.ok = prefilter_setting() && L.kp > 0 && n >= 65536 && L.exact.qwb == 4 &&
+           (image ? (ip || mode == MS_MODE_COSINE_UNIT) : (ip && loader_wave_setting() != 0));
+    L.exact_grid_max = L.exact.grid; L.exact_P_max = L.exact.P;
+    if (!L.ok) { L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0; return L; }
+    // two query tiles per wave (8 per workgroup) from 5 query tiles, while the lists leave room for it
+    const int qpw = image ? ((L.exact.n_qtiles >= 5 && L.kp <= 32) ? 2 : 1) : 0;
+    L.pf = make_plan(n, nq, L.kp, cus, qpw);
+    // the exact pass runs over 1 .. nq queries, decomposed on the device: the launch grid and the merge's LDS cover every case
+    size_t lists_max = 0;        // (its partial lists: nq_pad * P entries per rank, whichever decomposition the device picks)
+    for (int qt = 1; qt <= L.exact.n_qtiles; ++qt) {
+        ScanDevPlan d;
+        ms_plan_core(n, qt * 32 < nq ? qt * 32 : nq, cus, &d);
+        if (d.grid > L.exact_grid_max) L.exact_grid_max = d.grid;
+        if (d.P > L.exact_P_max) L.exact_P_max = d.P;
+        if ((size_t)d.nq_pad * d.P > lists_max) lists_max = (size_t)d.nq_pad * d.P;
+    }
     size_t off = L.pf.total > L.exact.total ? L.pf.total : L.exact.total;
-    L.off_as = off; off += ms_align_up((size_t)L.pf.nq_pad * L.kp * sizeof(float), 256);
-    L.off_ai = off; off += ms_align_up((size_t)L.pf.nq_pad * L.kp * sizeof(int64_t), 256);
+    const int nq_pad = L.pf.nq_pad > L.exact.nq_pad ? L.pf.nq_pad : L.exact.nq_pad;
+    L.off_as = off;     off += ms_align_up((size_t)nq_pad * L.kp * sizeof(float), 256);
+    L.off_ai = off;     off += ms_align_up((size_t)nq_pad * L.kp * sizeof(int64_t), 256);
+    L.off_flag = off;   off += ms_align_up((size_t)nq_pad * sizeof(uint32_t), 256);
+    L.off_qn_c = off;   off += ms_align_up((size_t)nq_pad * MS_DIM * sizeof(float), 256);
+    L.off_lb_c = off;   off += ms_align_up((size_t)nq_pad * sizeof(float), 256);
+    L.off_qlen_c = off; off += ms_align_up((size_t)nq_pad * sizeof(float), 256);
+    L.off_qmap = off;   off += ms_align_up((size_t)nq_pad * sizeof(int), 256);
+    L.off_dp = off;     off += 256;
+    L.off_xs = off;     off += ms_align_up(lists_max * L.exact.k_pass * sizeof(float), 256);
+    L.off_xi = off;     off += ms_align_up(lists_max * L.exact.k_pass * sizeof(uint32_t), 256);
     L.total = off;
     return L;
 }
-int pf_run(int stages, const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
-           float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, hipStream_t st) {
-    int rc = check_search_args(db, n, q, nq, k, mode, nullptr, nullptr, nullptr);
+int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+           const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores, int64_t *out_idx,
+           void *workspace, size_t workspace_bytes, hipStream_t st) {
+    int rc = check_search_args(db, n, q, nq, k, mode, nullptr, lengths, qlen);
     if (rc) return rc;
-    const PfLayout L = pf_layout(n, nq, k, mode);
+    if (mode == MS_MODE_COSINE_RAW) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: MS_MODE_COSINE_RAW is not served (normalise the rows once: MS_MODE_COSINE_UNIT)");
+    const PfLayout L = pf_layout(n, nq, k, mode, image != nullptr);
     if (workspace == nullptr || workspace_bytes < L.total)
         MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_prefiltered: workspace %zu < %zu bytes", workspace_bytes, L.total);
     char *blk = L.ok && row_norm_bound > 0.0f && row_norm_bound < INFINITY ? sync_block_for(workspace) : nullptr;
     if (blk == nullptr) {          // shapes the prefilter does not serve: the fp32 path, same stages
-        if (stages == 7) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, out_scores, out_idx, workspace, workspace_bytes, st);
-        if (stages == 1) return ms_ip_topk_prepare(db, n, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, workspace, workspace_bytes, st);
-        if (stages == 2) return ms_ip_topk_scan(db, n, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, workspace, workspace_bytes, st);
+        if (stages == 7) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, lengths, qlen, mincov, out_scores, out_idx, workspace, workspace_bytes, st);
+        if (stages == 1) return ms_ip_topk_prepare(db, n, q, nq, k, mode, nullptr, lengths, qlen, mincov, workspace, workspace_bytes, st);
+        if (stages == 2) return ms_ip_topk_scan(db, n, q, nq, k, mode, nullptr, lengths, qlen, mincov, workspace, workspace_bytes, st);
         return ms_ip_topk_finish(n, row_offset, nq, k, out_scores, out_idx, workspace, workspace_bytes, st);
     }
     char *ws = (char *)workspace;
     const ScanPlan &pl = L.pf;
     ScanParams sp;
     if (stages & 1) {
-        rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, nullptr, nullptr, 0.0f, ws, st, &sp);
+        rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, lengths, qlen, mincov, ws, st, &sp);
         if (rc) return rc;
-        sp.prefilter = 1;
+        sp.prefilter = 1; sp.pf_image = image;
         rc = run_prepass(pl, &sp, nq, ws, st);
         if (rc) return rc;
         if (sp.hist != nullptr) hist_mark_clean(workspace, n, nq, L.kp);
     } else {
-        fill_scan_params(pl, db, n, q, nq, nullptr, nullptr, nullptr, 0.0f, ws, mode, &sp);
-        sp.prefilter = 1;
+        fill_scan_params(pl, db, n, q, nq, nullptr, lengths, qlen, mincov, ws, mode, &sp);
+        sp.prefilter = 1; sp.pf_image = image;
         if (pl.prepass_tiles > 0) {
             sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
             if (hist_setting()) {
@@ -1030,65 +1147,102 @@ int pf_run(int stages, const float *db, int64_t n, int64_t row_offset, const flo
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
         const uint32_t epoch = next_epoch();
         const ScanPlan &px = L.exact;
+        uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.off_flag);
         float *exact_lb = reinterpret_cast<float *>(ws + px.off_lb_s);
+        float *qn_c = reinterpret_cast<float *>(ws + L.off_qn_c), *lb_c = reinterpret_cast<float *>(ws + L.off_lb_c);
+        float *qlen_c = reinterpret_cast<float *>(ws + L.off_qlen_c);
+        int *qmap = reinterpret_cast<int *>(ws + L.off_qmap);
+        ScanDevPlan *dp = reinterpret_cast<ScanDevPlan *>(ws + L.off_dp);
         hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, MS_PF_ERR * row_norm_bound,
-                           out_scores, out_idx, gate, epoch, exact_lb);
+                           lengths, qlen, mincov, out_scores, out_idx, flag, exact_lb);
         MS_LAUNCH_CHECK("ms_rescore_kernel");
-        g_pf_last_epoch.store(epoch);
-        // the exact pipeline, gated: its two launches return at once unless some query raised the gate in ms_rescore_kernel.  No
-        // sample pass: the k-th best exact score among a query's candidates is already a lower bound on its k-th best (k rows
-        // score at least that), and a tight one.
+        hipLaunchKernelGGL(ms_compact_flagged_kernel, dim3(1), dim3(256), 0, st, flag, nq, n, cu_count_cached(), sp.qn, exact_lb, qlen, qn_c, lb_c,
+                           qlen_c, qmap, dp, gate, epoch);
+        MS_LAUNCH_CHECK("ms_compact_flagged_kernel");
+        // The exact pass, for the flagged queries ONLY (the reference's semantics are per query: dbsearch.py:234-242): an fp32 scan
+        // and a merge over the compacted batch, decomposed on the device (ScanDevPlan), both returning at once when no query was
+        // flagged.  No sample pass: the k-th best exact score among a query's candidates is already a lower bound on its k-th
+        // best (k rows score at least that), and a tight one.  Always the kernels for any number of query tiles (ms_scan_kernel).
         ScanParams sx;
-        fill_scan_params(px, db, n, q, nq, nullptr, nullptr, nullptr, 0.0f, ws, mode, &sx);
-        sx.qn = sp.qn;                       // (the queries prepared for the prefilter: same array, same place)
+        fill_scan_params(px, db, n, q, nq, nullptr, lengths, lengths != nullptr ? qlen_c : nullptr, mincov, ws, mode, &sx);
+        sx.qn = qn_c;                        // (prepared -- normalised where the mode asks for it -- by the prefilter's stage 1)
         sx.qnorm_eps = 0.0f;
         sx.gate = gate; sx.gate_epoch = epoch;
-        sx.lb_s = exact_lb;
+        sx.lb_s = lb_c;
         sx.k = px.k_pass;
-        rc = launch_scan(px, sx, st);
+        sx.dev_plan = dp;
+        sx.part_s = reinterpret_cast<float *>(ws + L.off_xs);
+        sx.part_i = reinterpret_cast<uint32_t *>(ws + L.off_xi);
+        ScanPlan pg = px;
+        pg.grid = L.exact_grid_max; pg.P = L.exact_P_max; pg.qwb = 1;     // (qwb = 1: routes to ms_scan_kernel, whose decomposition is the device plan's)
+        sx.qwb = 1;
+        rc = launch_scan(pg, sx, st);
         if (rc) return rc;
-        rc = launch_merge(px, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st);
+        rc = launch_merge(pg, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st, dp, qmap);
         if (rc) return rc;
     }
     return MS_OK;
 }
 }  // namespace
 
-size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k) {
-    if (n < 0 || nq < 1 || k < 1) return 0;
-    const size_t a = pf_layout(n, nq, k, MS_MODE_IP_PRENORM).total, b = make_plan(n, nq, k, cu_count_cached()).total;
-    return a > b ? a : b;
+size_t ms_pf_image_bytes(int64_t n) { return n < 0 ? 0 : (size_t)((n + 31) / 32) * 16384; }
+
+int ms_pf_build_image(const float *db, int64_t n, void *image, ms_stream_t stream) {
+    if (n < 0 || (n > 0 && (db == nullptr || image == nullptr))) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: bad arguments");
+    if (((uintptr_t)image & 15) != 0 || ((uintptr_t)db & 15) != 0) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: db and image must be 16-byte aligned");
+    if (n == 0) return MS_OK;
+    return ms_launch_pf_build_image(db, n, image, (hipStream_t)stream);
 }
 
-int ms_ip_topk_prefiltered(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
-                           float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
-    if (k > 64) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, nullptr, nullptr, 0.0f, out_scores, out_idx, workspace, workspace_bytes, stream);
-    return pf_run(7, db, n, row_offset, q, nq, k, mode, row_norm_bound, out_scores, out_idx, workspace, workspace_bytes, (hipStream_t)stream);
+size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k) {
+    if (n < 0 || nq < 1 || k < 1) return 0;
+    size_t m = make_plan(n, nq, k, cu_count_cached()).total;
+    for (int image = 0; image < 2; ++image) {
+        const size_t a = pf_layout(n, nq, k, image ? MS_MODE_COSINE_UNIT : MS_MODE_IP_PRENORM, image != 0).total;
+        if (a > m) m = a;
+    }
+    return m;
 }
-int ms_ip_topk_prefiltered_prepare(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound, void *workspace,
+
+int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+                           const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores,
+                           int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
+    if (k > 64) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, lengths, qlen, mincov, out_scores, out_idx, workspace, workspace_bytes, stream);
+    return pf_run(7, db, pf_image, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
+                  workspace_bytes, (hipStream_t)stream);
+}
+int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+                                   const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                    size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(1, db, n, 0, q, nq, k, mode, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+    return pf_run(1, db, pf_image, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
+                  (hipStream_t)stream);
 }
-int ms_ip_topk_prefiltered_scan(const float *db, int64_t n, const float *q, int nq, int k, int mode, float row_norm_bound, void *workspace,
+int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+                                const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                 size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(2, db, n, 0, q, nq, k, mode, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+    return pf_run(2, db, pf_image, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
+                  (hipStream_t)stream);
 }
-int ms_ip_topk_prefiltered_finish(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode, float row_norm_bound,
-                                  float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(4, db, n, row_offset, q, nq, k, mode, row_norm_bound, out_scores, out_idx, workspace, workspace_bytes, (hipStream_t)stream);
+int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+                                  const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores,
+                                  int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
+    return pf_run(4, db, pf_image, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
+                  workspace_bytes, (hipStream_t)stream);
 }
-// Diagnostics for the tests: did the last prefiltered search on this workspace need the exact pipeline?  (synchronises the device)
-int ms_debug_prefilter_gate(void *workspace, unsigned int *gate_value, unsigned int *last_epoch) {
+// Diagnostics for the tests (synchronises the device): the state the last prefiltered search on this workspace left behind --
+// *flagged = how many of its queries needed the exact pass (0: the prefilter proved every answer).
+int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned int *last_epoch, unsigned int *flagged) {
     char *blk = sync_block_for(workspace);
     if (blk == nullptr || hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(gate_value, blk + 256, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    *last_epoch = (unsigned int)(g_pf_last_epoch.load());
+    unsigned int w[3] = {0, 0, 0};
+    if (hipMemcpy(w, blk + 256, 12, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *gate_value = w[0]; *last_epoch = w[1]; *flagged = w[2];
     return 0;
 }
 
 // Diagnostics (tools/pf_try.py): the candidate lists (approximate scores, rows) the last prefiltered search left in the workspace.
-int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, float *as_host, int64_t *ai_host, int *kp_out) {
-    const PfLayout L = pf_layout(n, nq, k, MS_MODE_IP_PRENORM);
+int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, int image, float *as_host, int64_t *ai_host, int *kp_out) {
+    const PfLayout L = pf_layout(n, nq, k, MS_MODE_IP_PRENORM, image != 0);
     if (!L.ok || hipDeviceSynchronize() != hipSuccess) return -1;
     *kp_out = L.kp;
     if (hipMemcpy(as_host, (char *)workspace + L.off_as, (size_t)nq * L.kp * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;

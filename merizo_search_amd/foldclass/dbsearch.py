@@ -97,6 +97,8 @@ def _to_engine(target_dict: dict, engine) -> None:
     target_dict["row_lo"], target_dict["row_hi"] = lo, hi
     target_dict["database"] = engine.cosine_rows(engine.to_device(target_dict["database"][lo:hi].float().contiguous()))
     target_dict["lengths"] = engine.to_device(target_dict["lengths"][lo:hi])
+    # (large query batches: the prefiltered search over the split image of the normalised rows, built once here)
+    target_dict["pf_image"] = engine.pf_image(target_dict["database"]) if hasattr(engine, "pf_image") else None
     target_dict["_engine"] = engine
 
 
@@ -117,8 +119,9 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
     if topk > target_dict["n_rows"]:
         raise RuntimeError("selected index k out of range")
     q = engine.to_device(emb).reshape(-1, 128)
+    extra = {"pf_image": target_dict["pf_image"]} if target_dict.get("pf_image") is not None else {}
     scores, idx = engine.cosine_topk(target_dict["database"], q, int(topk), lengths=target_dict["lengths"],
-                                     qlen=engine.to_device(qlen), mincov=float(mincov), row_offset=target_dict["row_lo"])
+                                     qlen=engine.to_device(qlen), mincov=float(mincov), row_offset=target_dict["row_lo"], **extra)
     scores, idx = sharded.exchange_and_merge(scores, idx, engine)        # no-op on one rank
     if single:
         return {"scores": scores[0], "indices": idx[0]}
@@ -126,7 +129,7 @@ def search_query_against_db(query_dict, target_dict, mincov, topk, score_correct
 
 
 def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to_host: bool = True, raw_queries: bool = False,
-              row_norm_bound=None):
+              row_norm_bound=None, pf_image=None):
     """Exact max-inner-product kNN over a database delivered block by block (knn_exact_faiss,
     dbsearch.py:213-248): per block IndexFlat.add/search -> `I += i0` -> ResultHeap merge.
 
@@ -151,7 +154,9 @@ def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to
         ni = block.shape[0]
         if ni == 0:
             continue
-        s, i = (engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries, row_norm_bound=row_norm_bound)
+        # (a resident shard comes with its row-norm bound and, memory permitting, its split image: large batches then take the
+        #  prefiltered search -- same results)
+        s, i = (engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries, row_norm_bound=row_norm_bound, pf_image=pf_image)
                 if row_norm_bound is not None else engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries))
         if best_s is None:
             best_s, best_i = s, i
@@ -336,7 +341,7 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
         # search that is one launch (normalisation in the scan's prologue, merge by its last workgroup)
         # (more than 64 queries: the prefiltered search, with the shard's row-norm bound measured once when it became resident)
         Ds, Is = knn_exact(emb, [shard], int(topk), engine, row_offset=lo, to_host=False, raw_queries=True,
-                           row_norm_bound=target_dict["_resident"].get("row_norm_bound"))
+                           row_norm_bound=target_dict["_resident"].get("row_norm_bound"), pf_image=target_dict["_resident"].get("pf_image"))
     else:
         logger.info("database shard of %d rows exceeds the resident budget: streaming blocks of %d rows"
                     % (hi - lo, int(search_batchsize)))
@@ -345,8 +350,6 @@ def dbsearch_faiss(queries, target_dict: dict, tmp: str, network, topk: int, min
                            to_host=False)
     Ds, Is = sharded.exchange_and_merge(Ds, Is, engine)                   # all-gather + merge; no-op on one rank
     D, I = Ds.cpu().numpy(), Is.cpu().numpy()
-    if hasattr(engine, "prefilter_feedback"):
-        engine.prefilter_feedback(logger)       # (the copy above synchronised: reading the prefilter's gate costs nothing now)
     results = [dict() for _ in range(nq)]
     all_results = [dict() for _ in range(nq)]
     if rank != 0:
@@ -414,6 +417,7 @@ def _resident_shard(target_dict: dict, engine, dbmm, lo: int, hi: int, nq: int, 
     cache.update(engine=engine, span=(lo, hi), shard=engine.upload_rows(dbmm, lo, hi))
     if hasattr(engine, "row_norm_bound"):           # (the CPU oracle engine of the tests has no prefiltered search)
         cache["row_norm_bound"] = engine.row_norm_bound(cache["shard"])
+        cache["pf_image"] = engine.pf_image(cache["shard"])
     return cache["shard"]
 
 

@@ -12,9 +12,11 @@ Engine interface (tensors are torch tensors on the engine's device):
     normalize_(x, eps)                                      -> x, rows L2-normalised in place
     normalized(x, eps)                                      -> new tensor, rows L2-normalised (F.normalize)
     cosine_rows(db)                                         -> the resident form of a RAW `.pt` matrix for cosine_topk
-    cosine_topk(rows, q, k, lengths, qlen, mincov, row_offset) -> (scores [nq,k], idx int64 [nq,k])
-    ip_topk(db, q, k, row_offset, normalize_queries)        -> (scores [nq,k], idx int64 [nq,k]); normalize_queries: q raw,
-                                                               F.normalize (eps 1e-12) fused into the call
+    cosine_topk(rows, q, k, lengths, qlen, mincov, row_offset[, pf_image]) -> (scores [nq,k], idx int64 [nq,k])
+    ip_topk(db, q, k, row_offset, normalize_queries[, row_norm_bound, pf_image]) -> (scores [nq,k], idx int64 [nq,k]);
+                                                               normalize_queries: q raw, F.normalize (eps 1e-12) fused into the call
+    pf_image(db)                                            -> the split-bf16 image of a resident matrix for the prefiltered search
+                                                               (None when HBM has no room for it), built once per database
     topk_merge(scores [S,nq,k], idx [S,nq,k])               -> (scores [nq,k], idx [nq,k])
     merge_gathered(PackedExchange)                          -> (scores [nq,k], idx [nq,k])  multi-rank merge
     upload_rows(matrix, lo, hi)                             -> rows [lo,hi) of a host matrix as ONE device tensor
@@ -58,7 +60,6 @@ class HipEngine:
         self._state_dict = state_dict
         self._ws = ops.TopKWorkspace(self.device)
         self._pws = ops.PrefilterWorkspace(self.device)
-        self._pf_enabled, self._pf_fallbacks, self._pf_pending = True, 0, False
 
     # -- encoder ---------------------------------------------------------------------
     def load_weights(self, state_dict: dict) -> None:
@@ -106,37 +107,45 @@ class HipEngine:
         every search runs the scan in MS_MODE_COSINE_UNIT, at the inner-product rate.  The raw matrix stays on disk."""
         return self._ops.l2_normalize_rows_(db, 1e-8)
 
-    def cosine_topk(self, rows, q, k, lengths=None, qlen=None, mincov: float = 0.0, row_offset: int = 0):
-        return self._ops.ip_topk(rows, q, k, mode=self._ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
-                                 row_offset=row_offset, workspace=self._ws)
+    UNIT_ROW_BOUND = 1.0 + 1e-5      # |row| of rows normalised in fp32 (cosine_rows; dbfname_IP holds such rows too)
 
-    def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False, row_norm_bound=None):
+    def cosine_topk(self, rows, q, k, lengths=None, qlen=None, mincov: float = 0.0, row_offset: int = 0, pf_image=None):
+        """search_query_against_db's arithmetic on rows normalised once (cosine_rows).  pf_image (`pf_image(rows)`, built when the
+        database became resident): batches of more than 64 queries take the prefiltered search, same results bit for bit."""
+        ops = self._ops
+        if pf_image is not None and ops.prefilter_serves(rows.shape[0], q.shape[0], k):
+            return ops.ip_topk_prefiltered(rows, q, k, self.UNIT_ROW_BOUND, mode=ops.MODE_COSINE_UNIT, row_offset=row_offset,
+                                           workspace=self._pws, image=pf_image, lengths=lengths, qlen=qlen, mincov=mincov)
+        return ops.ip_topk(rows, q, k, mode=ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
+                           row_offset=row_offset, workspace=self._ws)
+
+    def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False, row_norm_bound=None, pf_image=None):
         """index.search of dbsearch.py:234-242.  row_norm_bound: an upper bound on the rows' L2 norms when the caller knows one
         (`row_norm_bound(db)` once per resident database): batches of more than 64 queries then take the prefiltered search
-        (ms_ip_topk_prefiltered: same results bit for bit, the rows scanned with bf16 matrix instructions on split operands)."""
-        mode = self._ops.MODE_IP_NORMQ if normalize_queries else self._ops.MODE_IP_PRENORM
-        if row_norm_bound is not None and q.shape[0] > 64 and k <= 48 and self._pf_enabled:
-            self._pf_pending = True
-            return self._ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws)
-        return self._ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
+        (ms_ip_topk_prefiltered: same results bit for bit; the rows scanned with bf16 matrix instructions -- over `pf_image`, the
+        split image built when the database became resident, or split in registers without one).  Queries whose answer the
+        prefilter cannot prove get an exact pass of their own inside the same call: no feedback loop, no switch."""
+        ops = self._ops
+        mode = ops.MODE_IP_NORMQ if normalize_queries else ops.MODE_IP_PRENORM
+        if row_norm_bound is not None and ops.prefilter_serves(db.shape[0], q.shape[0], k):
+            return ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws,
+                                           image=pf_image)
+        return ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
 
-    def prefilter_feedback(self, log=None):
-        """Call at a point where the search results have been copied to the host anyway (no extra synchronisation): did the last
-        prefiltered search need the exact pass as well?  A batch that does costs the prefilter's scan ON TOP of the fp32 one; a
-        database whose best hits are families of near-duplicates (dozens of rows within 2.5e-4 of the k-th best score) would do
-        so batch after batch, so two such batches in a row switch the prefilter off for this engine (the results were exact
-        either way)."""
-        if not getattr(self, "_pf_pending", False) or self._pws.buf is None:
-            return
-        self._pf_pending = False
-        if self._ops.prefilter_fell_back(self._pws.buf):
-            self._pf_fallbacks += 1
-            if self._pf_fallbacks >= 2:
-                self._pf_enabled = False
-                if log is not None:
-                    log.info("prefiltered search: the exact pass was needed twice in a row on this database; using the fp32 scan from now on")
-        else:
-            self._pf_fallbacks = 0
+    def pf_image(self, db, reserve: int = 6 << 30):
+        """The split-bf16 image of a resident matrix (ops.pf_build_image: +512 B per row; the fp32 rows stay for the exact
+        re-scoring), or None when HBM has no room for it next to `reserve` bytes of workspace -- the prefiltered search then splits
+        the rows in registers (inner-product modes) or the fp32 scan runs (cosine)."""
+        from .. import _lib
+        n = int(db.shape[0])
+        if n < _lib.PREFILTER_MIN_ROWS or os.environ.get("MERIZO_PF_IMAGE", "1") == "0":
+            return None
+        need = int(_lib.load().ms_pf_image_bytes(n))
+        free, _total = self.torch.cuda.mem_get_info(self.device)
+        if need + reserve > free:
+            logger.info("no room for the prefilter's split image (%d MiB, %d MiB free): splitting rows in registers" % (need >> 20, free >> 20))
+            return None
+        return self._ops.pf_build_image(db)
 
     def row_norm_bound(self, db) -> float:
         """max |row| over a resident database, a hair up (one HBM pass; the prefiltered search's error bound scales with it)."""
@@ -211,9 +220,10 @@ class HipEngine:
         free, total = self.torch.cuda.mem_get_info(self.device)
         margin = (2 << 30) + total // 50 + 2 * self.STAGE_ROWS * 512
         rows_est = max(1, min((free - margin) // 512, (1 << 31) - 2))
-        with self.torch.cuda.device(self.device):
-            ws = int(_lib.load().ms_ip_topk_workspace_bytes(int(rows_est), max(1, int(nq)), max(1, int(k))))
+        with self.torch.cuda.device(self.device):        # (the prefiltered search's workspace covers the plain one's)
+            ws = int(_lib.load().ms_ip_topk_prefiltered_workspace_bytes(int(rows_est), max(1, int(nq)), max(1, int(k))))
         ws += 3 * 12 * max(1, int(nq)) * max(1, int(k))            # outputs + PackedExchange blocks
+        ws += 4 * int(rows_est)                                     # row_norm_bound's one float per row, right after the upload
         return max(0, int(free - margin - ws))
 
     def _staging(self, rows: int):

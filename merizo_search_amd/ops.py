@@ -164,17 +164,52 @@ class PrefilterWorkspace(TopKWorkspace):
         return self.buf
 
 
-def ip_topk_prefiltered(db, q, k: int, row_norm_bound: float = 1.0, mode: int = MODE_IP_PRENORM, row_offset: int = 0,
-                        workspace=None, out=None):
-    """ip_topk in the inner-product modes with the same results bit for bit, several times faster for more than 64 queries
-    and k <= 32 (split-bf16 prefilter + exact re-scoring + per-query proof, exact fp32 pipeline behind it when the proof fails;
-    include/merizo_search_amd.h).  row_norm_bound: an upper bound on every row's L2 norm (1.0 for unit rows).
-    workspace: a PrefilterWorkspace or a uint8 tensor of ms_ip_topk_prefiltered_workspace_bytes."""
+def pf_build_image(db, out=None):
+    """The split-bf16 image of a resident database for the prefiltered search (ms_pf_build_image): 512 B per row next to the fp32
+    rows, built once.  -> uint8 tensor of ms_pf_image_bytes(n)."""
     torch = _lib.require_gpu()
     _f32_cuda(db, "db", DIM)
+    n = db.shape[0]
+    need = int(_lib.load().ms_pf_image_bytes(n))
+    img = torch.empty(max(need, 16), dtype=torch.uint8, device=db.device) if out is None else out
+    if img.dtype != torch.uint8 or img.numel() < need or not img.is_contiguous():
+        raise MerizoHipError("pf_build_image: out must be a contiguous uint8 tensor of ms_pf_image_bytes(n)")
+    with _on(db, img) as dev:
+        check(_lib.load().ms_pf_build_image(ptr(db), n, ptr(img), dev.stream), "ms_pf_build_image")
+    return img
+
+
+def prefilter_serves(n: int, nq: int, k: int) -> bool:
+    """The shapes ms_ip_topk_prefiltered serves itself (everything else it hands to ms_ip_topk): ONE statement of the rule for the
+    engine, the bench and the tests (the library applies the same in pf_layout)."""
+    return nq > 64 and k <= _lib.PREFILTER_MAX_K and n >= _lib.PREFILTER_MIN_ROWS
+
+
+def _pf_args(db, image, q, mode, lengths, qlen):
+    _f32_cuda(db, "db", DIM)
     _f32_cuda(q, "q", DIM)
-    if mode not in (MODE_IP_PRENORM, MODE_IP_NORMQ):
-        raise MerizoHipError("ip_topk_prefiltered: inner-product modes only")
+    if mode not in (MODE_IP_PRENORM, MODE_IP_NORMQ, MODE_COSINE_UNIT):
+        raise MerizoHipError("ip_topk_prefiltered: MODE_IP_PRENORM, MODE_IP_NORMQ or MODE_COSINE_UNIT")
+    if mode != MODE_COSINE_UNIT and (lengths is not None or qlen is not None):
+        raise MerizoHipError("ip_topk_prefiltered: lengths / qlen go with MODE_COSINE_UNIT")
+    if image is not None and (image.dtype.itemsize != 1 or image.numel() < int(_lib.load().ms_pf_image_bytes(db.shape[0]))):
+        raise MerizoHipError("ip_topk_prefiltered: image is not pf_build_image(db)")
+    for name, t, size in (("lengths", lengths, db.shape[0]), ("qlen", qlen, q.shape[0])):
+        if t is not None:
+            _f32_cuda(t, name)
+            if t.numel() != size:
+                raise MerizoHipError(f"{name}: expected {size} elements, got {t.numel()}")
+
+
+def ip_topk_prefiltered(db, q, k: int, row_norm_bound: float = 1.0, mode: int = MODE_IP_PRENORM, row_offset: int = 0,
+                        workspace=None, out=None, image=None, lengths=None, qlen=None, mincov: float = 0.0):
+    """ip_topk with the same results bit for bit, several times faster for more than 64 queries and k <= 48: split-bf16 prefilter
+    scan (over `image` = pf_build_image(db) when given, else splitting the rows in registers), exact re-scoring, per-query proof,
+    and an exact fp32 pass over the queries whose proof failed (include/merizo_search_amd.h).  row_norm_bound: an upper bound on
+    every row's L2 norm (1.0 + 1e-6 for unit rows).  workspace: a PrefilterWorkspace or a uint8 tensor of
+    ms_ip_topk_prefiltered_workspace_bytes."""
+    torch = _lib.require_gpu()
+    _pf_args(db, image, q, mode, lengths, qlen)
     n, nq = db.shape[0], q.shape[0]
     ws = workspace if isinstance(workspace, torch.Tensor) else (workspace or PrefilterWorkspace(db.device)).get(n, nq, k)
     if out is None:
@@ -182,36 +217,43 @@ def ip_topk_prefiltered(db, q, k: int, row_norm_bound: float = 1.0, mode: int = 
         out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
     else:
         out_s, out_i = out
-    with _on(db, q, ws, out_s, out_i) as dev:
-        check(_lib.load().ms_ip_topk_prefiltered(ptr(db), n, row_offset, ptr(q), nq, k, mode, float(row_norm_bound), ptr(out_s),
-                                                 ptr(out_i), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered")
+    with _on(db, q, ws, out_s, out_i, image, lengths, qlen) as dev:
+        check(_lib.load().ms_ip_topk_prefiltered(ptr(db), ptr(image), n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+                                                 float(row_norm_bound), ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream),
+              "ms_ip_topk_prefiltered")
     return out_s, out_i
 
 
 def ip_topk_prefiltered_stage(stage: str, db, q, k: int, ws, row_norm_bound: float = 1.0, mode: int = MODE_IP_PRENORM,
-                              out=None, row_offset: int = 0):
+                              out=None, row_offset: int = 0, image=None, lengths=None, qlen=None, mincov: float = 0.0):
     """One stage of ip_topk_prefiltered ('prepare', 'scan', 'finish'): lets a bench time the scan launch alone."""
     lib = _lib.load()
     n, nq = db.shape[0], q.shape[0]
-    with _on(db, q, ws) as dev:
+    with _on(db, q, ws, image, lengths, qlen) as dev:
         if stage == "prepare":
-            check(lib.ms_ip_topk_prefiltered_prepare(ptr(db), n, ptr(q), nq, k, mode, float(row_norm_bound), ptr(ws), ws.numel(),
-                                                     dev.stream), "ms_ip_topk_prefiltered_prepare")
+            check(lib.ms_ip_topk_prefiltered_prepare(ptr(db), ptr(image), n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+                                                     float(row_norm_bound), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered_prepare")
         elif stage == "scan":
-            check(lib.ms_ip_topk_prefiltered_scan(ptr(db), n, ptr(q), nq, k, mode, float(row_norm_bound), ptr(ws), ws.numel(),
-                                                  dev.stream), "ms_ip_topk_prefiltered_scan")
+            check(lib.ms_ip_topk_prefiltered_scan(ptr(db), ptr(image), n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+                                                  float(row_norm_bound), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered_scan")
         else:
             out_s, out_i = out
-            check(lib.ms_ip_topk_prefiltered_finish(ptr(db), n, row_offset, ptr(q), nq, k, mode, float(row_norm_bound), ptr(out_s),
-                                                    ptr(out_i), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered_finish")
+            check(lib.ms_ip_topk_prefiltered_finish(ptr(db), ptr(image), n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+                                                    float(row_norm_bound), ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream),
+                  "ms_ip_topk_prefiltered_finish")
+
+
+def prefilter_flagged(ws) -> int:
+    """Diagnostics (synchronises): how many queries of the last prefiltered search on this workspace needed the exact pass."""
+    import ctypes
+    g, e, c = ctypes.c_uint(0), ctypes.c_uint(0), ctypes.c_uint(0)
+    check(_lib.load().ms_debug_prefilter_state(ptr(ws), ctypes.byref(g), ctypes.byref(e), ctypes.byref(c)), "ms_debug_prefilter_state")
+    return int(c.value) if e.value != 0 else 0
 
 
 def prefilter_fell_back(ws) -> bool:
-    """Diagnostics (synchronises): did the last prefiltered search on this workspace run the exact pipeline as well?"""
-    import ctypes
-    g, e = ctypes.c_uint(0), ctypes.c_uint(0)
-    check(_lib.load().ms_debug_prefilter_gate(ptr(ws), ctypes.byref(g), ctypes.byref(e)), "ms_debug_prefilter_gate")
-    return g.value == e.value and e.value != 0
+    """Diagnostics (synchronises): did any query of the last prefiltered search on this workspace need the exact pass?"""
+    return prefilter_flagged(ws) > 0
 
 
 def topk_merge(scores, idx):

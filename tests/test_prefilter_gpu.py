@@ -1,6 +1,7 @@
 """GPU parity of the prefiltered search (ms_ip_topk_prefiltered): the rows are scanned with bf16 matrix instructions on split
-operands, the survivors re-scored with the exact fp32 chain, and every query's answer is proved complete -- or the exact
-pipeline runs after all.  The bar is the one of ms_ip_topk: indices AND score bits identical to the oracle."""
+operands -- over the split image built once per database (ms_pf_build_image), or splitting in registers without one -- the
+survivors re-scored with the exact fp32 chain, and every query's answer is proved complete -- or that query gets an exact
+pass of its own.  The bar is the one of ms_ip_topk: indices AND score bits identical to the oracle."""
 import numpy as np
 import pytest
 
@@ -24,12 +25,16 @@ def _norm_db(n, seed):
     return syn.normalized_database(n, seed)
 
 
-def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fallback=None):
+def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fallback=None, image=True, expect_flagged=None):
     d, dq = _dev(torch, db), _dev(torch, q)
     ws = ops.PrefilterWorkspace(d.device).get(db.shape[0], q.shape[0], k)
     mode = ops.MODE_IP_NORMQ if raw else ops.MODE_IP_PRENORM
-    s, i = ops.ip_topk_prefiltered(d, dq, k, bound, mode=mode, row_offset=row_offset, workspace=ws)
-    fell_back = ops.prefilter_fell_back(ws)
+    img = ops.pf_build_image(d) if image else None
+    s, i = ops.ip_topk_prefiltered(d, dq, k, bound, mode=mode, row_offset=row_offset, workspace=ws, image=img)
+    flagged = ops.prefilter_flagged(ws)
+    fell_back = flagged > 0
+    if expect_flagged is not None:       # (a family may also sit inside the candidate range of a query that does not own it: a few more)
+        assert expect_flagged <= flagged <= expect_flagged + max(4, expect_flagged // 2), (flagged, expect_flagged)
     qn = ops.l2_normalize_rows(dq, 1e-12).cpu().numpy() if raw else q      # (the library's own F.normalize: ms_l2_normalize_rows_to)
     s_ref, i_ref = orc.ip_topk(db, qn, k, row_offset=row_offset, order=1)
     assert np.array_equal(i.cpu().numpy(), i_ref)
@@ -39,18 +44,21 @@ def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fal
     return fell_back
 
 
+@pytest.mark.parametrize("image", [True, False])
 @pytest.mark.parametrize("n,nq,k", [(70_000, 65, 1), (70_000, 100, 5), (131_105, 97, 10), (300_000, 256, 10), (262_113, 130, 16),
-                                    (400_000, 200, 20), (200_000, 129, 32), (300_000, 100, 40), (1_000_003, 256, 10), (100_000, 1000, 3)])
-def test_prefiltered_is_bit_identical_and_needs_no_exact_pass_on_ordinary_data(n, nq, k, torch_gpu):
+                                    (400_000, 200, 20), (200_000, 129, 32), (300_000, 100, 40), (1_000_003, 256, 10), (100_000, 1000, 3),
+                                    (65_536, 160, 10), (99_999, 161, 7), (250_000, 300, 48)])
+def test_prefiltered_is_bit_identical_and_needs_no_exact_pass_on_ordinary_data(n, nq, k, image, torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops
     from oracle import oracle as orc
     db, q = _norm_db(n, seed=401 + k), _norm_db(nq, seed=402)
     db[n - 1] = db[3]; db[n // 2] = db[3]                     # a few exact duplicates (ties resolve to the lowest row)
-    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=11, expect_fallback=False)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=11, expect_fallback=False, image=image)
 
 
-def test_prefiltered_raw_queries_and_rows_that_are_not_unit_vectors(torch_gpu):
+@pytest.mark.parametrize("image", [True, False])
+def test_prefiltered_raw_queries_and_rows_that_are_not_unit_vectors(image, torch_gpu):
     """MS_MODE_IP_NORMQ (F.normalize inside the call) and a database whose rows have norms 0.2 .. 3: the error bound scales with
     the row-norm bound the caller measured."""
     torch = torch_gpu
@@ -62,14 +70,15 @@ def test_prefiltered_raw_queries_and_rows_that_are_not_unit_vectors(torch_gpu):
     db = (_norm_db(n, seed=411) * rng.uniform(0.2, 3.0, size=(n, 1))).astype(np.float32)
     q_raw, _ = syn.raw_queries(nq, seed=412)
     bound = float(np.linalg.norm(db.astype(np.float64), axis=1).max()) * (1 + 1e-6)
-    _check(torch, ops, orc, db, (q_raw * 2.5).astype(np.float32), k, bound, raw=True, expect_fallback=False)
+    _check(torch, ops, orc, db, (q_raw * 2.5).astype(np.float32), k, bound, raw=True, expect_fallback=False, image=image)
     q = (_norm_db(nq, seed=413) * 4.0).astype(np.float32)    # MS_MODE_IP_PRENORM with queries that are not unit vectors either
-    _check(torch, ops, orc, db, q, k, bound)
+    _check(torch, ops, orc, db, q, k, bound, image=image)
 
 
-def test_prefiltered_near_ties_by_the_hundred_fall_back_to_the_exact_pipeline(torch_gpu):
+@pytest.mark.parametrize("image", [True, False])
+def test_prefiltered_near_ties_by_the_hundred_fall_back_to_the_exact_pipeline(image, torch_gpu):
     """300 rows within 1e-6 of each other around every query's best score (copies of the query's own direction with tiny
-    perturbations) and blocks of exact duplicates: the proof cannot succeed, the gate opens, the exact pipeline answers."""
+    perturbations) and blocks of exact duplicates: no proof can succeed, every query gets the exact pass."""
     torch = torch_gpu
     from merizo_search_amd import ops
     from oracle import oracle as orc
@@ -81,8 +90,107 @@ def test_prefiltered_near_ties_by_the_hundred_fall_back_to_the_exact_pipeline(to
         v = q[j][None, :] + rng.normal(0, 2e-7, size=(300, 128)).astype(np.float32)
         db[rows[j]] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
     db[rows[0, :50]] = db[rows[0, 0]]                         # exact ties too
-    fell_back = _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, expect_fallback=True)
+    fell_back = _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, expect_fallback=True, image=image, expect_flagged=nq)
     assert fell_back
+
+
+def _family(rng, qvec, count, sigma=2e-7):
+    v = qvec[None, :] + rng.normal(0, sigma, size=(count, 128)).astype(np.float32)
+    return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("which", ["one", "seventeen", "all", "tile_edges", "last_only"])
+def test_queries_whose_proof_fails_get_an_exact_pass_of_their_own(which, torch_gpu):
+    """Per-query exact fallback (the reference's semantics are per query: dbsearch.py:234-242): only the queries that own a family
+    of 200 near-duplicates fail their proof; they are compacted on the device, scanned exactly and scattered back; every other
+    query keeps the prefilter's (proved) answer.  All 256 answers == the oracle's, and the flagged count is exactly the planted one."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, nq, k = 200_000, 256, 10
+    db, q = _norm_db(n, seed=491), _norm_db(nq, seed=492)
+    owners = {"one": [77], "seventeen": list(range(5, 256, 15))[:17], "all": list(range(256)),
+              "tile_edges": [0, 31, 32, 63, 64, 95, 96, 127, 128, 159, 160, 191, 192, 223, 224, 255], "last_only": [255]}[which]
+    rng = np.random.default_rng(8)
+    rows = rng.choice(n, size=(len(owners), 200), replace=False)
+    for j, qi in enumerate(owners):
+        db[rows[j]] = _family(rng, q[qi], 200)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=3, expect_flagged=len(owners))
+
+
+def test_flagged_queries_in_a_large_batch_and_long_lists(torch_gpu):
+    """1000 queries, k = 32 (64 candidates per query), 40 owners of 300-row families: compaction across several query groups."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, nq, k = 150_000, 1000, 32
+    db, q = _norm_db(n, seed=493), _norm_db(nq, seed=494)
+    owners = list(range(3, 1000, 25))
+    rng = np.random.default_rng(9)
+    rows = rng.choice(n, size=(len(owners), 300), replace=False)
+    for j, qi in enumerate(owners):
+        db[rows[j]] = _family(rng, q[qi], 300)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, expect_flagged=len(owners))
+
+
+def _cosine_case(n, nq, seed, masked_fraction=0.5):
+    from merizo_search_amd.foldclass import synthetic as syn
+    rng = np.random.default_rng(seed)
+    db = (_norm_db(n, seed=seed) * rng.uniform(0.5, 2.0, size=(n, 1))).astype(np.float32)
+    q, _ = syn.raw_queries(nq, seed=seed + 1)
+    lengths = rng.integers(40, 400, size=n).astype(np.float32)
+    qlen = rng.integers(40, 400, size=nq).astype(np.float32)
+    return db, q.astype(np.float32), lengths, qlen
+
+
+@pytest.mark.parametrize("n,nq,k,mincov", [(200_000, 256, 10, 0.7), (131_071, 100, 5, 0.0), (300_000, 1000, 10, 0.7), (100_000, 130, 20, 1.5),
+                                           (70_000, 97, 1, 0.7)])
+def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, torch_gpu):
+    """MS_MODE_COSINE_UNIT through the prefilter (search_query_against_db on rows normalised once, dbsearch.py:75-81): the length
+    mask multiplies the approximate and the exact score by the same 0 / 1, so the proof holds; results == ms_ip_topk's bit for bit
+    and == the oracle's cosine_topk (near-tie aware)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    from conftest import assert_topk_equivalent
+    db, q, lengths, qlen = _cosine_case(n, nq, seed=500 + k)
+    d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
+    unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
+    img = ops.pf_build_image(unit)
+    ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=mincov)
+    s0, i0 = ops.ip_topk(unit, dq, k, row_offset=7, **kw)
+    s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, row_offset=7, workspace=ws, image=img, **kw)
+    assert ops.prefilter_flagged(ws) == 0
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    sel = np.arange(0, nq, max(1, nq // 40))
+    s_ref, i_ref = orc.cosine_topk(db, q[sel], k, lengths, qlen[sel], mincov, row_offset=7)
+    assert_topk_equivalent(s1.cpu().numpy()[sel], i1.cpu().numpy()[sel], s_ref, i_ref, tol=2e-6)
+
+
+def test_prefiltered_cosine_with_every_row_masked_and_with_families(torch_gpu):
+    """Everything masked for some queries (all scores +-0: ties by the thousand, resolved by row; those queries fail their proof and
+    get the exact pass) and near-duplicate families for others."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    n, nq, k = 120_000, 200, 10
+    db, q, lengths, qlen = _cosine_case(n, nq, seed=520)
+    qlen[:5] = 1.0                                             # shorter than every row * mincov: everything masked
+    rng = np.random.default_rng(10)
+    rows = rng.choice(n, size=(6, 150), replace=False)
+    for j in range(6):
+        db[rows[j]] = _family(rng, q[50 + j] / np.linalg.norm(q[50 + j]), 150) * 1.3
+        lengths[rows[j]] = 50.0
+        qlen[50 + j] = 300.0
+    d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
+    unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
+    img = ops.pf_build_image(unit)
+    ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=0.7)
+    s0, i0 = ops.ip_topk(unit, dq, k, **kw)
+    s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, workspace=ws, image=img, **kw)
+    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    assert ops.prefilter_flagged(ws) >= 11
 
 
 @pytest.mark.parametrize("n,nq,k", [(300_000, 40, 10), (300_000, 100, 49), (20_000, 100, 10), (300_000, 100, 100)])
@@ -94,25 +202,27 @@ def test_prefiltered_shapes_it_does_not_serve_take_the_plain_path(n, nq, k, torc
     _check(torch, ops, orc, _norm_db(n, seed=431), _norm_db(nq, seed=432), k, 1.0 + 1e-6)
 
 
-def test_prefiltered_stages_equal_the_one_shot_call_and_repeat(torch_gpu):
+@pytest.mark.parametrize("image", [True, False])
+def test_prefiltered_stages_equal_the_one_shot_call_and_repeat(image, torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops
     n, nq, k = 500_000, 256, 10
     db, q = _norm_db(n, seed=441), _norm_db(nq, seed=442)
     d, dq = _dev(torch, db), _dev(torch, q)
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    img = ops.pf_build_image(d) if image else None
     s0, i0 = ops.ip_topk(d, dq, k)
     out = (torch.empty_like(s0), torch.empty_like(i0))
     for _ in range(3):
-        ops.ip_topk_prefiltered_stage("prepare", d, dq, k, ws)
-        ops.ip_topk_prefiltered_stage("scan", d, dq, k, ws)
-        ops.ip_topk_prefiltered_stage("finish", d, dq, k, ws, out=out)
+        ops.ip_topk_prefiltered_stage("prepare", d, dq, k, ws, image=img)
+        ops.ip_topk_prefiltered_stage("scan", d, dq, k, ws, image=img)
+        ops.ip_topk_prefiltered_stage("finish", d, dq, k, ws, out=out, image=img)
         assert torch.equal(out[1], i0) and torch.equal(out[0].view(torch.int32), s0.view(torch.int32))
         out[0].zero_(); out[1].zero_()
-    ops.ip_topk_prefiltered_stage("prepare", d, dq, k, ws)
+    ops.ip_topk_prefiltered_stage("prepare", d, dq, k, ws, image=img)
     for _ in range(2):                                         # the same workspace scanned twice after one prepare
-        ops.ip_topk_prefiltered_stage("scan", d, dq, k, ws)
-        ops.ip_topk_prefiltered_stage("finish", d, dq, k, ws, out=out)
+        ops.ip_topk_prefiltered_stage("scan", d, dq, k, ws, image=img)
+        ops.ip_topk_prefiltered_stage("finish", d, dq, k, ws, out=out, image=img)
         assert torch.equal(out[1], i0) and torch.equal(out[0].view(torch.int32), s0.view(torch.int32))
 
 
@@ -125,9 +235,12 @@ def test_engine_uses_the_prefilter_for_large_batches_on_a_resident_database(torc
     d, dq = _dev(torch, db), _dev(torch, (q * 3).astype(np.float32))
     bound = e.row_norm_bound(d)
     assert 1.0 <= bound < 1.0001
-    s1, i1 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True, row_norm_bound=bound)
+    img = e.pf_image(d)
+    assert img is not None and img.numel() >= 512 * d.shape[0]
     s0, i0 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True)
-    assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+    for image in (img, None):
+        s1, i1 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True, row_norm_bound=bound, pf_image=image)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
 
 
 def test_prefiltered_shards_merge_to_the_unsharded_answer(torch_gpu):
@@ -144,7 +257,7 @@ def test_prefiltered_shards_merge_to_the_unsharded_answer(torch_gpu):
     parts = []
     for lo, hi in ((0, 170_000), (170_000, n)):
         shard = d[lo:hi].contiguous()
-        parts.append(e.ip_topk(shard, dq, k, row_offset=lo, row_norm_bound=e.row_norm_bound(shard)))
+        parts.append(e.ip_topk(shard, dq, k, row_offset=lo, row_norm_bound=e.row_norm_bound(shard), pf_image=e.pf_image(shard)))
     s, i = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(i, i_all) and torch.equal(s.view(torch.int32), s_all.view(torch.int32))
 
@@ -165,9 +278,9 @@ def test_prefiltered_declines_databases_with_non_finite_rows(torch_gpu):
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
 
 
-def test_engine_switches_the_prefilter_off_after_two_batches_that_needed_the_exact_pass(torch_gpu):
-    """foldclass/engine.py: near-duplicate families make every batch run both scans; after two in a row the engine uses the fp32
-    scan for this database.  Results are exact before and after."""
+def test_engine_keeps_the_prefilter_on_clustered_data_batch_after_batch(torch_gpu):
+    """foldclass/engine.py: near-duplicate families for a quarter of the queries; every batch flags exactly those and stays on the
+    prefiltered path (no two-strikes switch any more: a clustered query costs only itself).  Results exact every time."""
     torch = torch_gpu
     from merizo_search_amd import ops
     from merizo_search_amd.foldclass import engine as eng
@@ -175,31 +288,31 @@ def test_engine_switches_the_prefilter_off_after_two_batches_that_needed_the_exa
     n, nq, k = 150_000, 96, 10
     db, q = _norm_db(n, seed=481), _norm_db(nq, seed=482)
     rng = np.random.default_rng(7)
-    rows = rng.choice(n, size=(nq, 100), replace=False)
-    for j in range(nq):
-        v = q[j][None, :] + rng.normal(0, 2e-7, size=(100, 128)).astype(np.float32)
-        db[rows[j]] = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    owners = list(range(0, nq, 4))
+    rows = rng.choice(n, size=(len(owners), 100), replace=False)
+    for j, qi in enumerate(owners):
+        db[rows[j]] = _family(rng, q[qi], 100)
     d, dq = _dev(torch, db), _dev(torch, q)
-    bound = e.row_norm_bound(d)
+    bound, img = e.row_norm_bound(d), e.pf_image(d)
     s0, i0 = ops.ip_topk(d, dq, k)
     for call in range(4):
-        s, i = e.ip_topk(d, dq, k, row_norm_bound=bound)
+        s, i = e.ip_topk(d, dq, k, row_norm_bound=bound, pf_image=img)
         assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
-        s.cpu()
-        e.prefilter_feedback()
-        assert e._pf_enabled == (call < 1)
+        assert len(owners) <= ops.prefilter_flagged(e._pws.buf) <= len(owners) + 4
 
 
+@pytest.mark.parametrize("image", [True, False])
 @pytest.mark.parametrize("k", [10, 40])
-def test_prefiltered_repeated_searches_return_identical_results(k, torch_gpu):
+def test_prefiltered_repeated_searches_return_identical_results(k, image, torch_gpu):
     """Run-to-run determinism of the prefiltered search (100 runs of one search; the first against the fp32 scan)."""
     torch = torch_gpu
     from merizo_search_amd import ops
     n, nq = 202_000, 738
     d, dq = _dev(torch, _norm_db(n, seed=46)), _dev(torch, _norm_db(nq, seed=47))
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    img = ops.pf_build_image(d) if image else None
     s_ref, i_ref = ops.ip_topk(d, dq, k)
     for _ in range(100):
-        s, i = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, workspace=ws)
+        s, i = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, workspace=ws, image=img)
         assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32))
     assert not ops.prefilter_fell_back(ws)

@@ -18,35 +18,38 @@ of 12*nq*k bytes per rank and one merge per step.  queries/s is then (nearly) co
 database grows N-fold; the N = 1 point of that curve is the `c4_shard` entry of the default run.
 `--rows R` overrides either default with R total rows sharded over the ranks (strong scaling).
 
-More than 64 queries and k <= 32 (the headline and c4_shard): the step runs the PREFILTERED search (ms_ip_topk_prefiltered: the
-rows scanned once with bf16 matrix instructions on operands split in registers, the best 2k rows per query re-scored with
-the exact fp32 chain, the answer proved complete per query, the exact fp32 pass gated behind it) -- bit-identical results;
-`fp32_path` times the same step through the fp32 scan and checks the two results against each other; `--no-prefilter` makes
-the fp32 scan the headline.
+The top-level line is the fp32 scan (ms_ip_topk_prepare / _scan / _finish): the reference's own arithmetic, data-independent.  The
+PREFILTERED search (ms_ip_topk_prefiltered: the rows scanned once with bf16 matrix instructions over the split-bf16 image built
+when the database became resident, the best 2k rows per query re-scored with the exact fp32 chain, the answer proved complete per
+query, an exact fp32 pass for the queries whose proof failed) -- what the driver runs for more than 64 queries, bit-identical
+results -- is the named block `prefiltered` beside it, with its own dtype, roofs and traffic; `--no-prefilter` skips those blocks.
 
 One JSON line is printed by rank 0 (contract in the task statement), with
-  roofline      dominant kernel.  Prefiltered: its scan launch against the dense bf16 matrix peak (3 bf16 matrix instructions'
-                flops per dimension block) from 208 queries, against the HBM peak below.  fp32 scan
-                (ms_scan_loader_kernel; ms_scan_kernel below 3 query tiles):
-                algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the scan
-                launch against the fp32 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic
-                bytes (512 B per row) against the 8 TB/s HBM peak; both fractions always included,
-                plus `step_frac`: the same work over the whole step time (what the user gets);
-                `traffic` (HBM bytes per launch) is NOT measured by this run -- counters need the profiler --
-                but copied from the PMC passes of the same workload committed under profiles/ (r03_c2_pmc.json,
-                r03_c4_pmc.json, r03_c3_pmc.json): `traffic_from_committed_profile` / `traffic_source` say so;
+  roofline      dominant kernel of the top-level step, the fp32 scan launch (ms_scan_loader_kernel; ms_scan_kernel below 3 query
+                tiles): algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the launch against the fp32
+                MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic bytes (512 B per row) against the 8 TB/s HBM peak; both
+                fractions always included, plus `step_frac`: the same work over the whole step time (what the user gets);
+                `traffic` (HBM bytes per launch) is NOT measured by this run -- counters need the profiler -- but copied from the
+                PMC passes of the same workload committed under profiles/: `traffic_from_committed_profile` / `traffic_source`;
+  prefiltered   (N = 1) the same step through the prefiltered search: ms per step, q/s, identical_to_fp32, how many queries needed
+                the exact pass, and the roofs of ITS scan launch (ms_scan_pf2_kernel): the algorithmic flops UN-tripled, the
+                flops it executes (3 bf16 matrix instructions per 16 dimensions) against the dense bf16 matrix peak, the bytes of
+                the image (512 B per row) against the HBM peak;
+  clustered     (N = 1) C2 with 64 of the 256 queries owning a family of 200 near-duplicate rows (within 1e-6 of each other): the
+                prefilter cannot prove those 64 answers and gives exactly them an exact pass; both paths timed;
   cpu_baseline  the CPU oracle (oracle/oracle.c: AVX2 + OpenMP port of the faiss path) on this host's
                 cores, and under `torch_cpu` the reference's own torch op shapes (oracle/torch_baseline.py)
                 -- per-query cosine_similarity*mask->topk, blockwise-262,144 normalize->Q@D^T->topk->merge,
                 batch=1 EGNN loop; all on bounded samples;
   hbm_regime    (N = 1) nq = 1 / 4 / 8 / 32 over 1M, 4M and 45.6M rows: GB/s against the HBM peak;
-  c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries;
-  k_sweep       (N = 1) the C2 shape at k = 1 / 10 / 20 / 32 / 64;
+  c4_shard      (N = 1) one rank's share of C4: 45,625,000 rows x 4096 queries, fp32 scan and prefiltered;
+  k_sweep       (N = 1) the C2 shape at k = 1 / 10 / 20 / 32 / 64, both paths;
   c3_search     (N = 1) C3's search half: 500k rows of a `.pt` database (normalised once at load, as the product does),
-                1000 queries, cosine + length mask;
+                1000 queries, cosine + length mask, fp32 scan and prefiltered;
   embed         (N = 1) C3's embed half: 1000 TED-length domains -> embeds/s and fraction of the fp32 MFMA
-                peak, and the C5 query (AF-Q96PD2, 3 domains) latency.
-`--no-extras` skips the last three, `--no-cpu-baseline` the CPU legs.
+                peak, and the C5 query (AF-Q96PD2, 3 domains) latency;
+  c3_end_to_end (N = 1) C3 as ONE timed unit: embed 1000 domains, then search their embeddings against the 500k-row database.
+`--no-extras` skips everything from hbm_regime down, `--no-cpu-baseline` the CPU legs.
 """
 import argparse
 import json
@@ -70,39 +73,47 @@ def scan_kernel_name(nq, k):
     return "ms_scan_loader_kernel" if (nq > 64 and k <= 64) else "ms_scan_kernel"
 
 
-def small_batch_note(nq):
+def small_batch_note(nq, ops=None):
+    """What one step of <= 64 queries launches, from the thresholds the loaded library applies (ms_small_batch_thresholds)."""
     if nq > 64:
         return None
-    return ("one ms_ip_topk call per step (MS_MODE_IP_NORMQ): scan_ms = HIP events around that call = " +
-            ("ONE launch (normalise in the scan's prologue, merge by its last workgroup)" if nq <= 8 else
-             "sample pass + bound + scan (normalise in its prologue) + merge launches"))
+    fused, inkernel = ops.small_batch_thresholds() if ops is not None else (2, 4)
+    norm = "normalise in the scan's prologue" if nq <= inkernel else "query preparation launch (F.normalize)"
+    if nq <= fused:
+        what = "ONE launch (%s, merge by the scan's last workgroup)" % norm
+    elif nq < 8:
+        what = "%s%s scan + merge launches (no sample pass below 8 queries)" % (norm, "," if nq <= inkernel else " +")
+    else:
+        what = "%s%s sample pass + bound + scan + merge launches" % (norm, "," if nq <= inkernel else " +")
+    return "one ms_ip_topk call per step (MS_MODE_IP_NORMQ): scan_ms = HIP events around that call = " + what
 
 
 def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
     """Both roofs for one scan launch over `rows` rows; the binding one is `frac`.
-    prefiltered: the scan of ms_ip_topk_prefiltered scores with bf16 matrix instructions (3 per fp32 one's worth of k), far
-    below the bf16 matrix roof; what is left to bound it is the one read of the rows: the HBM roof."""
+    prefiltered: the scan of ms_ip_topk_prefiltered over the split-bf16 image issues 3 bf16 matrix instructions per 16 dimensions
+    (hi.hi, hi.lo, lo.hi): its matrix roof is 3 x the algorithmic flops over the dense bf16 peak, its memory roof the one read of
+    the image (512 B per row, like the fp32 rows)."""
     flops = 2.0 * 128 * nq * rows
     bytes_ = 512.0 * rows
     t = scan_ms * 1e-3
     mfma_frac, hbm_frac = flops / t / MFMA_F32_PEAK, bytes_ / t / HBM_PEAK
     if prefiltered:
-        # three bf16 matrix instructions' worth of flops per fp32 one: T_bf16 = 3 * flops / 2.5e15 against T_hbm: matrix-bound from 208 queries
-        bf16_frac = 3.0 * flops / t / MFMA_BF16_PEAK
-        if nq >= 208:
-            roof = {"bound": "mfma", "achieved": 3.0 * flops / t / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": bf16_frac,
-                    "step_frac": 3.0 * flops / (step_ms * 1e-3) / MFMA_BF16_PEAK}
+        executed = 3.0 * flops
+        bf16_frac = executed / t / MFMA_BF16_PEAK
+        matrix_bound = executed / MFMA_BF16_PEAK >= bytes_ / HBM_PEAK           # from 208 queries
+        if matrix_bound:
+            roof = {"bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": bf16_frac,
+                    "step_frac": executed / (step_ms * 1e-3) / MFMA_BF16_PEAK}
         else:
             roof = {"bound": "hbm", "achieved": bytes_ / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac,
                     "step_frac": bytes_ / (step_ms * 1e-3) / HBM_PEAK}
-        roof.update({"traffic": None,
-                     "kernel": "ms_scan_loader_kernel<KL, 0, false, true> (prefilter: split-bf16 scores; ms_rescore_kernel makes them exact)",
-                     "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "bf16_mfma_frac": bf16_frac, "fp32_mfma_equivalent_frac": mfma_frac,
-                     "rows_per_launch": rows, "algorithmic_bytes_per_launch": bytes_, "algorithmic_flops_per_launch": 3.0 * flops,
-                     "note": "peak = the dense bf16 matrix peak (the scan issues 3 bf16 matrix instructions per 16 dimensions: hi.hi, hi.lo, lo.hi); "
-                             "bound in practice by vector-instruction issue: every compute wave splits the tile's floats into bf16 hi / lo "
-                             "itself, ~230 vector instructions per 24 matrix instructions (DESIGN.md 5.5); fp32_mfma_equivalent_frac = the "
-                             "fp32 scan's flops over this launch's time against the fp32 matrix peak (> 1: no fp32-matrix kernel can be this fast)"})
+        roof.update({"traffic": None, "kernel": "ms_scan_pf2_kernel (split-bf16 image; ms_rescore_kernel makes the scores exact)",
+                     "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "split_bf16_mfma_frac": bf16_frac,
+                     "algorithmic_tflops": flops / t / 1e12, "rows_per_launch": rows, "algorithmic_bytes_per_launch": bytes_,
+                     "algorithmic_flops_per_launch": flops, "executed_bf16_flops_per_launch": executed,
+                     "note": "achieved / frac (matrix-bound shapes) count the flops the launch EXECUTES: 3 bf16 matrix instructions per 16 "
+                             "dimensions = 3 x the algorithmic flops, against the dense bf16 matrix peak -- the roof of this arithmetic; "
+                             "algorithmic_tflops is the un-tripled figure (it may exceed the fp32 matrix peak: this is not fp32 matrix work)"})
         return roof
     if nq >= 39:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": mfma_frac,
@@ -134,8 +145,9 @@ def attach_committed_traffic(roof, pmc_name):
 class SearchBench:
     """One shard resident on this rank + a query batch; `step()` is the timed unit."""
 
-    def __init__(self, torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=False, prefilter=True):
-        self.torch, self.dist, self.ops, self.world = torch, dist, ops, world
+    def __init__(self, torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=False, prefilter=False,
+                 clustered=0):
+        self.torch, self.dist, self.ops, self.world, self.sharded = torch, dist, ops, world, sharded
         self.n_total, self.lo, self.n_local, self.nq, self.k = n_total, lo, hi - lo, nq, k
         self.exchange = exchange or world > 1
         # synthetic inputs (SURVEY.md 8d): unit rows ~ N(0,1)/|.| (seed 0, independent of the sharding); raw
@@ -154,19 +166,45 @@ class SearchBench:
         mine = (flat >= lo) & (flat < hi)
         if mine.any():
             self.db[(flat[mine] - lo).to(dev)] = near.reshape(-1, 128)[mine].to(dev)
+        self.clustered = int(clustered)
+        if self.clustered:
+            # `clustered` of the queries own a family of 200 rows within ~1e-6 of each other (copies of the query's direction with
+            # 2e-7 noise: the construction of tools/stress_prefilter.py): no prefilter can prove those answers
+            owners = torch.arange(0, nq, max(1, nq // self.clustered))[: self.clustered]
+            fam = qn[owners][:, None, :] + torch.randn((len(owners), 200, 128), generator=gp) * 2e-7
+            fam = fam / fam.norm(dim=2, keepdim=True)
+            rows = ((torch.arange(len(owners) * 200, dtype=torch.int64) * step_ + 777_777) % n_total)
+            mine = (rows >= lo) & (rows < hi)
+            self.db[(rows[mine] - lo).to(dev)] = fam.reshape(-1, 128)[mine].to(dev)
+            self.cluster_owners = owners
         self.q = torch.empty_like(self.q_raw)
-        # more than 64 queries, k <= 32: the prefiltered search (same results bit for bit: ms_ip_topk_prefiltered), as the driver
-        # runs it on a resident shard; its error bound needs the largest row norm, measured once here as the driver does
-        self.prefilter = prefilter and nq > 64 and k <= 32 and self.n_local >= 65536
-        self.row_norm_bound = (float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)) if self.prefilter else None
-        self.ws = torch.empty_like((ops.PrefilterWorkspace if self.prefilter else ops.TopKWorkspace)(dev).get(self.n_local, nq, k))
         self.ex = sharded.PackedExchange(nq, k, dev)     # this rank's results are written straight into its all-gather block
+        self.image = self.row_norm_bound = None
+        self._set_path(prefilter)
+
+    def _set_path(self, prefilter):
+        """fp32 scan (ms_ip_topk stages) or, for the shapes it serves, the prefiltered search as the driver runs it on a resident
+        shard: split image built once, the largest row norm measured once."""
+        ops, dev = self.ops, self.db.device
+        self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_local, self.nq, self.k)
+        if self.prefilter and self.image is None:
+            self.row_norm_bound = float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)
+            self.image = ops.pf_build_image(self.db)
+        self.ws = self.torch.empty_like((ops.PrefilterWorkspace if self.prefilter else ops.TopKWorkspace)(dev).get(self.n_local, self.nq, self.k))
+
+    def variant(self, prefilter):
+        """The same database and queries through the other path."""
+        b = SearchBench.__new__(SearchBench)
+        b.__dict__.update(self.__dict__)
+        b.ex = self.sharded.PackedExchange(self.nq, self.k, self.db.device)
+        b._set_path(prefilter)
+        return b
 
     def step(self, events=None):
         ops, ex = self.ops, self.ex
         if self.nq <= 64:
             # the reference's own CLI regime (a few query domains, dbsearch.py:531-546): ONE C-ABI call, as the driver makes it
-            # (dbsearch.knn_exact(raw_queries=True)) -- F.normalize inside the scan launch, and up to 8 queries the merge too
+            # (dbsearch.knn_exact(raw_queries=True)) -- F.normalize and, for a handful of queries, the merge inside the scan launch
             if events is not None:
                 events[0].record()
             ops.ip_topk(self.db, self.q_raw, self.k, mode=ops.MODE_IP_NORMQ, row_offset=self.lo, workspace=self.ws, out=(ex.out_s, ex.out_i))
@@ -178,15 +216,15 @@ class SearchBench:
             return ex.out_s, ex.out_i
         ops.l2_normalize_rows(self.q_raw, 1e-12, out=self.q)                # F.normalize of the batch's raw embeddings (dbsearch.py:303-304)
         if self.prefilter:
-            b = self.row_norm_bound
-            ops.ip_topk_prefiltered_stage("prepare", self.db, self.q, self.k, self.ws, b)       # sample pass on approximate scores
+            kw = dict(row_norm_bound=self.row_norm_bound, image=self.image)
+            ops.ip_topk_prefiltered_stage("prepare", self.db, self.q, self.k, self.ws, **kw)       # sample pass on approximate scores
             if events is not None:
                 events[0].record()
-            ops.ip_topk_prefiltered_stage("scan", self.db, self.q, self.k, self.ws, b)          # dominant kernel: ONE scan launch
+            ops.ip_topk_prefiltered_stage("scan", self.db, self.q, self.k, self.ws, **kw)          # dominant kernel: ONE scan launch
             if events is not None:
                 events[1].record()
-            # merge of the candidate lists, exact re-scoring + proof, and the (gated: normally empty) exact pipeline
-            ops.ip_topk_prefiltered_stage("finish", self.db, self.q, self.k, self.ws, b, out=(ex.out_s, ex.out_i), row_offset=self.lo)
+            # merge of the candidate lists, exact re-scoring + proof, and the exact pass over the flagged queries (normally none)
+            ops.ip_topk_prefiltered_stage("finish", self.db, self.q, self.k, self.ws, out=(ex.out_s, ex.out_i), row_offset=self.lo, **kw)
             if self.exchange:
                 ex.exchange()
                 return ex.merge()
@@ -281,16 +319,29 @@ def hbm_regime(make, rows_list, log):
             out.append({"rows": rows, "nq": nq, "k": b.k, "ms_per_step": ms, "scan_ms": scan_ms, "queries_per_s": nq / ms * 1e3,
                         "scan_GBps": 512.0 * rows / scan_ms / 1e6, "scan_frac_of_hbm_peak": 512.0 * rows / (scan_ms * 1e-3) / HBM_PEAK,
                         "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k),
-                        "note": small_batch_note(nq)})
+                        "note": small_batch_note(nq, b.ops)})
             log("hbm_regime rows=%d nq=%d: call %.3f ms (%.1f%% of 8 TB/s), step %.3f ms (%.1f%%)" % (rows, nq, scan_ms, out[-1]["scan_frac_of_hbm_peak"] * 100, ms, out[-1]["step_frac_of_hbm_peak"] * 100))
             del b
     return out
 
 
-def c3_search_bench(torch, ops, syn, dev, k, log):
+def _timed_stages(torch, step, steps, warm=10):
+    for _ in range(warm):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t = time.perf_counter()
+    for s_ in range(steps):
+        step(evs[s_])
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / steps * 1e3, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+
+def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
     """C3's search half: a `.pt`-style database of 500,000 RAW rows, 1000 query embeddings, cosine + length mask
     (search_query_against_db, dbsearch.py:75-81; mincov 0.7).  As in the product (foldclass/engine.py:cosine_rows) the rows are
-    L2-normalised once when the database becomes resident and every search runs in MS_MODE_COSINE_UNIT."""
+    L2-normalised once when the database becomes resident and every search runs in MS_MODE_COSINE_UNIT: through the fp32 scan
+    (top-level numbers of the entry) and through the prefiltered search over the split image of the unit rows (`prefiltered`)."""
     n, nq, mincov = 500_000, 1000, 0.7
     db = syn.device_database(n, 0, seed=3, device=dev, normalize=False) * 2.5
     lengths = torch.from_numpy(syn.ted_lengths(n, seed=4).astype(np.float32)).to(dev)
@@ -312,17 +363,7 @@ def c3_search_bench(torch, ops, syn, dev, k, log):
             ev[1].record()
         ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
 
-    for _ in range(10):
-        step()
-    torch.cuda.synchronize()
-    steps = 40
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t = time.perf_counter()
-    for s_ in range(steps):
-        step(evs[s_])
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t) / steps * 1e3
-    scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    ms, scan_ms = _timed_stages(torch, step, 40)
     # check: masked cosine of the returned rows, recomputed in float64, and order
     rows = db[out_i.reshape(-1)].double().reshape(nq, k, 128)
     cos = (rows * q.double()[:, None, :]).sum(2) / rows.norm(dim=2) / q.double().norm(dim=1)[:, None]
@@ -333,10 +374,61 @@ def c3_search_bench(torch, ops, syn, dev, k, log):
            "roofline": roofline(nq, n, k, scan_ms, ms)}
     out["roofline"]["kernel"] = "ms_scan_loader_kernel<5, 2> (unit-row cosine variant: in-chain filter on the final scores, length mask in the rare path)"
     out["roofline"]["algorithmic_bytes_per_launch"] = 516.0 * n          # rows + their lengths
-    attach_committed_traffic(out["roofline"], "r03_c3_pmc.json")
+    attach_committed_traffic(out["roofline"], "r04_c3_pmc.json")
     log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
-    del db, unit, lengths, ws
-    return out
+    state = {"unit": unit, "lengths": lengths, "mincov": mincov, "n": n, "k": k, "image": None, "pws": None}
+    if prefilter and ops.prefilter_serves(n, nq, k):
+        img = ops.pf_build_image(unit)
+        pws = torch.empty_like(ops.PrefilterWorkspace(dev).get(n, nq, k))
+        ps, pi = torch.empty_like(out_s), torch.empty_like(out_i)
+        pkw = dict(row_norm_bound=1.0 + 1e-5, image=img, **kw)
+
+        def pstep(ev=None):
+            ops.ip_topk_prefiltered_stage("prepare", unit, q, k, pws, **pkw)
+            if ev is not None:
+                ev[0].record()
+            ops.ip_topk_prefiltered_stage("scan", unit, q, k, pws, **pkw)
+            if ev is not None:
+                ev[1].record()
+            ops.ip_topk_prefiltered_stage("finish", unit, q, k, pws, out=(ps, pi), **pkw)
+
+        pms, pscan = _timed_stages(torch, pstep, 40)
+        out["prefiltered"] = {"ms_per_step": pms, "queries_per_s": nq / pms * 1e3, "dtype": "bf16x3-split scan + f32 re-score",
+                              "identical_to_fp32": bool(torch.equal(pi, out_i) and torch.equal(ps.view(torch.int32), out_s.view(torch.int32))),
+                              "exact_pass_queries": ops.prefilter_flagged(pws), "roofline": roofline(nq, n, k, pscan, pms, prefiltered=True)}
+        attach_committed_traffic(out["prefiltered"]["roofline"], "r04_pf_c3_pmc.json")
+        log("c3_search prefiltered: %.3f ms per batch (scan %.3f ms), identical: %s, exact-pass queries: %d" % (
+            pms, pscan, out["prefiltered"]["identical_to_fp32"], out["prefiltered"]["exact_pass_queries"]))
+        state.update(image=img, pws=pws)
+    del db, ws
+    return out, state
+
+
+def c3_end_to_end(torch, ops, enc, coords, lens, state, log):
+    """C3 as BASELINE.json states it -- embed 1,000 domains, then search them against the 500k-row database -- as ONE timed unit:
+    CA coordinates on the host -> ragged encoder launches -> embeddings stay on the device -> cosine + length-mask top-k (the
+    prefiltered search when the image exists, as the driver would run it) -> results on the device."""
+    dev = state["unit"].device
+    qlen = torch.from_numpy(np.asarray(lens, dtype=np.float32)).to(dev)
+    k, n = state["k"], state["n"]
+    nq = len(coords)
+    ws = state["pws"] if state["image"] is not None else torch.empty_like(ops.TopKWorkspace(dev).get(n, nq, k))
+    kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=state["lengths"], qlen=qlen, mincov=state["mincov"])
+
+    def unit_of_work():
+        emb = enc.embed(coords)
+        if state["image"] is not None:
+            return ops.ip_topk_prefiltered(state["unit"], emb, k, 1.0 + 1e-5, workspace=ws, image=state["image"], **kw)
+        return ops.ip_topk(state["unit"], emb, k, workspace=ws, **kw)
+
+    unit_of_work(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter(); unit_of_work(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t)
+    sec = float(np.median(ts))
+    log("c3_end_to_end: %.1f ms for embed 1000 + search 500k = %.0f domains/s" % (sec * 1e3, nq / sec))
+    return {"workload": "C3: Foldclass EGNN embed %d TED-length domains + cosine/length-mask top-%d search of their embeddings over a 500,000 x 128 database, one timed unit" % (nq, k),
+            "seconds": sec, "domains_per_s": nq / sec, "search_path": "prefiltered (split image)" if state["image"] is not None else "fp32 scan"}
 
 
 def embed_bench(torch, ops, log):
@@ -375,7 +467,7 @@ def embed_bench(torch, ops, log):
         out["c5_query"]["embed_ms_whole_chain_N%d" % len(whole)] = tw * 1e3
         out["c5_query"]["whole_chain_frac_of_mfma_peak"] = fw / tw / MFMA_F32_PEAK
     log("embed: %.1f ms per 1000 domains = %.0f embeds/s = %.1f%% of fp32 MFMA peak" % (t1000 * 1e3, out["embeds_per_s"], out["roofline"]["frac"] * 100))
-    return out, sd, coords
+    return out, sd, coords, enc, lens
 
 
 def cpu_baseline(db, q_unit, k, n_total, sd, embed_coords):
@@ -440,7 +532,7 @@ def main():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip hbm_regime / c4_shard / embed")
-    ap.add_argument("--no-prefilter", action="store_true", help="time the fp32 scan (ms_ip_topk) instead of the prefiltered search")
+    ap.add_argument("--no-prefilter", action="store_true", help="skip the `prefiltered` blocks (the top-level line is the fp32 scan either way)")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
     args = ap.parse_args()
@@ -498,17 +590,42 @@ def main():
     lo, hi = sharded.shard_bounds(n_total, world, rank)
     log = (lambda m: print("[bench] " + m, file=sys.stderr, flush=True)) if rank == 0 else (lambda m: None)
 
-    bench = SearchBench(torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=args.exercise_exchange,
-                        prefilter=not args.no_prefilter)
+    use_pf = not args.no_prefilter
+    bench = SearchBench(torch, dist, ops, syn, sharded, dev, rank, world, n_total, lo, hi, nq, k, exchange=args.exercise_exchange)
     steps = args.steps
-    elapsed, scan_ms, res = bench.run(steps, args.warmup)
+    elapsed, scan_ms, res = bench.run(steps, args.warmup)        # the fp32 scan: the reference's arithmetic, data-independent
     checks = bench.check(res, sharded)
+
+    def pf_block(b_fp32, res_fp32, steps_, warm_, prep_s=0.3, pmc=None):
+        """The same step through the prefiltered search (the path the driver takes for this shape)."""
+        bp = b_fp32.variant(True)
+        if not bp.prefilter:
+            return None
+        torch.cuda.synchronize()
+        el, sc, rp = bp.run(steps_, warm_, prep_budget_s=prep_s)
+        ms = el / steps_ * 1e3
+        blk = {"ms_per_step": ms, "queries_per_s": bp.nq / ms * 1e3, "dtype": "bf16x3-split scan + f32 re-score",
+               "identical_to_fp32": bool(torch.equal(rp[1], res_fp32[1]) and torch.equal(rp[0].view(torch.int32), res_fp32[0].view(torch.int32))),
+               "exact_pass_queries": ops.prefilter_flagged(bp.ws) if world == 1 else None,
+               "split_image_bytes": int(bp.image.numel()),
+               "roofline": roofline(bp.nq, bp.n_local, bp.k, sc, ms, prefiltered=True),
+               "note": "ms_ip_topk_prefiltered over the split-bf16 image built when the database became resident (512 B per row next to the "
+                       "fp32 rows); the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, an exact "
+                       "fp32 pass for the queries whose proof failed (exact_pass_queries of them); results bit-identical to the fp32 scan "
+                       "(tests/test_prefilter_gpu.py)"}
+        if pmc is not None:
+            attach_committed_traffic(blk["roofline"], pmc)
+        del bp
+        return blk
+
+    c2 = (n_total, nq, k, world) == (1_000_000, 256, 10, 1)
+    pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r04_pf_c2_pmc.json" if c2 else None) if use_pf else None
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
-        roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step, prefiltered=bench.prefilter)
-        if world == 1 and (n_total, nq, k) == (1_000_000, 256, 10):
-            attach_committed_traffic(roof, "r03_pf_c2_pmc.json" if bench.prefilter else "r03_c2_pmc.json")
+        roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
+        if c2:
+            attach_committed_traffic(roof, "r04_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
         elif weak:
@@ -523,46 +640,43 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "db_rows": n_total, "rows_per_gpu": bench.n_local, "dim": 128, "queries_per_step": nq, "k": k,
                        "score": "inner product of L2-normalised rows (normalisation of the query batch inside the step)",
+                       "path": "fp32 scan (ms_ip_topk_prepare / _scan / _finish): v_mfma_f32_32x32x2_f32, the reference's arithmetic; the prefiltered "
+                               "search of the same step is the block `prefiltered`",
                        "sharding": "contiguous row shards, one RCCL all-gather of per-shard top-k + merge per step" if world > 1 else "single shard",
                        "scaling_note": "weak: rows per GPU fixed, the database grows with N, so ideal queries/s is CONSTANT in N (row x query "
                                        "rate grows N-fold); compare with c4_shard of the N=1 run" if weak else None},
             "row_queries_per_s": float(n_total) * nq * steps / elapsed,
             "roofline": roof,
-            "prefilter": {"used": bool(bench.prefilter),
-                          "exact_pipeline_ran": bool(ops.prefilter_fell_back(bench.ws)) if bench.prefilter else None,
-                          "note": "ms_ip_topk_prefiltered: rows scanned once with bf16 matrix instructions on operands split in registers, "
-                                  "the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, the exact fp32 "
-                                  "pipeline queued behind (it ran only if exact_pipeline_ran); results bit-identical to the fp32 scan "
-                                  "(tests/test_prefilter_gpu.py); the fp32 scan itself: entry fp32_path"},
+            "prefiltered": pf_main,
         }
         line.update(checks)
+        if pf_main is not None:
+            log("prefiltered: %.4f ms per step = %.0f q/s, scan %.1f us, identical to the fp32 scan: %s, exact-pass queries: %s" % (
+                pf_main["ms_per_step"], pf_main["queries_per_s"], pf_main["roofline"]["kernel_ms"] * 1e3, pf_main["identical_to_fp32"], pf_main["exact_pass_queries"]))
     else:
         line = None
-
-    if world == 1 and rank == 0:
-        if bench.prefilter:
-            # the same step through the fp32 scan (ms_ip_topk_prepare / _scan / _finish): the kernel the MFMA roofline of rounds 1-3 is about
-            b32 = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, k, prefilter=False)
-            torch.cuda.synchronize(); time.sleep(1.5)       # (the prefiltered steps leave the GPU at a lower clock for a moment)
-            el, sc, r32 = b32.run(100, 10, prep_budget_s=1.0, max_prep=1000)
-            ms32 = el / 100 * 1e3
-            line["fp32_path"] = {"workload": line["config"]["workload"] + " -- fp32 scan, no prefilter", "ms_per_step": ms32, "queries_per_s": nq / ms32 * 1e3,
-                                 "identical_to_prefiltered": bool(torch.equal(r32[1], res[1]) and torch.equal(r32[0].view(torch.int32), res[0].view(torch.int32))),
-                                 "roofline": roofline(nq, n_total, k, sc, ms32)}
-            if (n_total, nq, k) == (1_000_000, 256, 10):
-                attach_committed_traffic(line["fp32_path"]["roofline"], "r03_c2_pmc.json")
-            log("fp32_path: %.4f ms per step, scan %.1f us = %.1f%% of fp32 MFMA peak; identical to the prefiltered results: %s" % (
-                ms32, sc * 1e3, line["fp32_path"]["roofline"]["frac"] * 100, line["fp32_path"]["identical_to_prefiltered"]))
-            del b32, r32
 
     extras_sd, extras_coords = None, None
     if world == 1 and not args.no_extras:
         db_keep, q_keep = bench.db, bench.q_raw
         del bench.ws
-        mk = lambda rows, nq_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k, prefilter=not args.no_prefilter)
+        mk = lambda rows, nq_, **kw_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k, **kw_)
+        if use_pf and c2:
+            # C2 on clustered data: 64 of the 256 queries own a family of 200 near-duplicate rows
+            bc = mk(n_total, nq, clustered=64)
+            elc, scc, rc_ = bc.run(60, 10, prep_budget_s=0.1)
+            msc = elc / 60 * 1e3
+            pfc = pf_block(bc, rc_, 60, 10, prep_s=0.1)
+            line["clustered"] = {"workload": "C2 with 64 of the 256 queries owning a family of 200 rows within ~1e-6 of each other (no proof possible for them)",
+                                 "fp32_path": {"ms_per_step": msc, "queries_per_s": nq / msc * 1e3, "scan_ms": scc},
+                                 "prefiltered": pfc}
+            log("clustered: fp32 %.4f ms per step; prefiltered %.4f ms per step, %s queries through the exact pass, identical: %s" % (
+                msc, pfc["ms_per_step"], pfc["exact_pass_queries"], pfc["identical_to_fp32"]))
+            del bc, rc_
+            torch.cuda.empty_cache()
         line["hbm_regime"] = hbm_regime(mk, (1_000_000, 4_000_000), log)
         free, _tot = torch.cuda.mem_get_info(dev)
-        if free > 40 << 30:
+        if free > 70 << 30:
             big = mk(C4_ROWS_PER_GPU, C4_NQ)
             el, sc, r4 = big.run(2, 1, prep_budget_s=0.0)
             ms4 = el / 2 * 1e3
@@ -570,23 +684,16 @@ def main():
             planted4 = float(np.mean([len(set(big.planted[j].tolist()) & set(fi4[j].tolist())) / 3.0 for j in range(C4_NQ)]))
             line["c4_shard"] = {"workload": "one rank's share of C4: %d x 128 rows x %d queries, top-%d" % (C4_ROWS_PER_GPU, C4_NQ, k),
                                 "ms_per_step": ms4, "queries_per_s": C4_NQ / ms4 * 1e3, "planted_recall": planted4,
-                                "note": "queries_per_s here = the N-GPU rate on an N x 45.6M-row database, minus the all-gather + merge of 480 KB per rank",
-                                "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4, prefiltered=big.prefilter),
-                                "prefiltered": bool(big.prefilter),
-                                "exact_pipeline_ran": bool(ops.prefilter_fell_back(big.ws)) if big.prefilter else None}
-            log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (%s), scan %.1f ms" % (ms4, C4_NQ / ms4 * 1e3, "prefiltered" if big.prefilter else "fp32 scan", sc))
-            if big.prefilter:       # the fp32 scan on the same shard
-                big.prefilter = False
-                big.ws = torch.empty_like(ops.TopKWorkspace(dev).get(big.n_local, C4_NQ, k))
-                el, sc, r4f = big.run(2, 1, prep_budget_s=0.0)
-                ms4f = el / 2 * 1e3
-                line["c4_shard"]["fp32_path"] = {"ms_per_step": ms4f, "queries_per_s": C4_NQ / ms4f * 1e3, "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4f),
-                                                 "identical_to_prefiltered": bool(torch.equal(r4f[1], r4[1]) and torch.equal(r4f[0].view(torch.int32), r4[0].view(torch.int32)))}
-                if k == 10:
-                    attach_committed_traffic(line["c4_shard"]["fp32_path"]["roofline"], "r03_c4_pmc.json")
-                log("c4_shard fp32 path: %.1f ms per batch, scan %.1f%% of fp32 MFMA peak, identical: %s" % (
-                    ms4f, line["c4_shard"]["fp32_path"]["roofline"]["frac"] * 100, line["c4_shard"]["fp32_path"]["identical_to_prefiltered"]))
-                del r4f
+                                "note": "queries_per_s here = the N-GPU rate on an N x 45.6M-row database, minus the all-gather + merge of 480 KB per rank "
+                                        "(a projection: no multi-GPU node was available to this build)",
+                                "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
+            if k == 10:
+                attach_committed_traffic(line["c4_shard"]["roofline"], "r04_c4_pmc.json")
+            log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (fp32 scan %.1f ms = %.1f%% of fp32 MFMA peak)" % (ms4, C4_NQ / ms4 * 1e3, sc, line["c4_shard"]["roofline"]["frac"] * 100))
+            if use_pf:
+                line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r04_pf_c4_pmc.json" if k == 10 else None)
+                p4 = line["c4_shard"]["prefiltered"]
+                log("c4_shard prefiltered: %.1f ms per batch = %.0f q/s, scan %.1f ms, identical: %s" % (p4["ms_per_step"], p4["queries_per_s"], p4["roofline"]["kernel_ms"], p4["identical_to_fp32"]))
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
             small = []
             for nq_ in (1, 4, 8, 32):
@@ -594,6 +701,7 @@ def main():
                 b.__dict__.update(big.__dict__)
                 b.nq, b.q_raw = nq_, big.q_raw[:nq_].contiguous()
                 b.q = torch.empty_like(b.q_raw)
+                b.prefilter = False
                 b.ws = torch.empty_like(ops.TopKWorkspace(dev).get(b.n_local, nq_, k))
                 b.ex = sharded.PackedExchange(nq_, k, dev)
                 el, sc, _ = b.run(6, 2, prep_budget_s=0.0)
@@ -601,24 +709,32 @@ def main():
                 small.append({"rows": C4_ROWS_PER_GPU, "nq": nq_, "k": k, "ms_per_step": ms, "scan_ms": sc, "queries_per_s": nq_ / ms * 1e3,
                               "scan_GBps": 512.0 * C4_ROWS_PER_GPU / sc / 1e6, "scan_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (sc * 1e-3) / HBM_PEAK,
                               "step_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq_, k),
-                              "note": small_batch_note(nq_)})
+                              "note": small_batch_note(nq_, ops)})
                 log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s)" % (C4_ROWS_PER_GPU, nq_, sc, small[-1]["scan_frac_of_hbm_peak"] * 100))
                 del b
             line["hbm_regime"] += small
             del big, r4
             torch.cuda.empty_cache()
-        # list length: the same C2 shape at other k (k <= 10 / 20 / 32 run the loader-wave kernel with 5 / 10 / 16 list entries
-        # per lane, k <= 64 the non-loader kernel with 32)
+        # list length: the same C2 shape at other k (lists of 5 / 10 / 16 / 32 entries per lane for k <= 10 / 20 / 32 / 64)
         line["k_sweep"] = []
         for kk in (1, 10, 20, 32, 64):
-            bk = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, kk, prefilter=not args.no_prefilter)
-            el, sc, _ = bk.run(40, 5, prep_budget_s=0.05)
-            line["k_sweep"].append({"k": kk, "ms_per_step": el / 40 * 1e3, "scan_ms": sc, "queries_per_s": nq * 40 / el,
-                                    "kernel": scan_kernel_name(nq, kk), "prefiltered": bool(bk.prefilter)})
-            log("k_sweep k=%d: %.3f ms per step (scan %.3f ms)" % (kk, el / 40 * 1e3, sc))
+            bk = SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, n_total, 0, n_total, nq, kk)
+            el, sc, rk = bk.run(40, 5, prep_budget_s=0.05)
+            ent = {"k": kk, "ms_per_step": el / 40 * 1e3, "scan_ms": sc, "queries_per_s": nq * 40 / el, "kernel": scan_kernel_name(nq, kk)}
+            if use_pf:
+                bp = bk.variant(True)
+                if bp.prefilter:
+                    elp, scp, rp = bp.run(40, 5, prep_budget_s=0.05)
+                    ent["prefiltered"] = {"ms_per_step": elp / 40 * 1e3, "scan_ms": scp,
+                                          "identical_to_fp32": bool(torch.equal(rp[1], rk[1]) and torch.equal(rp[0].view(torch.int32), rk[0].view(torch.int32)))}
+                del bp
+            line["k_sweep"].append(ent)
+            log("k_sweep k=%d: fp32 %.3f ms per step (scan %.3f ms)%s" % (kk, el / 40 * 1e3, sc, "; prefiltered %.3f ms" % ent["prefiltered"]["ms_per_step"] if "prefiltered" in ent else ""))
             del bk
-        line["c3_search"] = c3_search_bench(torch, ops, syn, dev, k, log)
-        line["embed"], extras_sd, extras_coords = embed_bench(torch, ops, log)
+        line["c3_search"], c3_state = c3_search_bench(torch, ops, syn, dev, k, log, prefilter=use_pf)
+        line["embed"], extras_sd, extras_coords, enc, lens = embed_bench(torch, ops, log)
+        line["c3_end_to_end"] = c3_end_to_end(torch, ops, enc, extras_coords, lens, c3_state, log)
+        del c3_state, enc
         bench.db, bench.q_raw = db_keep, q_keep
 
     if rank == 0:

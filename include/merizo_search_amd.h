@@ -36,6 +36,11 @@ int ms_version(void);
 const char *ms_last_error(void);
 int ms_device_count(void);
 int ms_device_cu_count(void);
+/* The few-query shortcuts of ms_ip_topk as this build applies them (defaults 2 and 4; the environment variables
+ * MS_FUSED_MERGE_MAX_NQ / MS_INKERNEL_NORM_MAX_NQ override them): up to *fused_merge_max_nq queries the scan launch merges its own
+ * lists (one launch per search), up to *inkernel_norm_max_nq queries MS_MODE_IP_NORMQ normalises inside the scan launch. */
+void ms_small_batch_thresholds(int *fused_merge_max_nq, int *inkernel_norm_max_nq);
+int ms_prefilter_max_k(void); /* MS_PREFILTER_MAX_K */
 
 /* ------------------------------------------------------------------ search ---------- */
 
@@ -50,8 +55,9 @@ int ms_device_cu_count(void);
                                  scores leave the matrix pipe final and the scan runs at the inner-product rate;
                                  queries are still given raw, lengths / qlen / mincov mask as in COSINE_RAW */
 #define MS_MODE_IP_NORMQ 3   /* the faiss path with its query normalisation fused in: q is RAW, F.normalize(q) (eps 1e-12,
-                                 dbsearch.py:303-304) is applied inside the call (for up to 64 queries inside the scan launch
-                                 itself), then knn_exact_faiss as in MS_MODE_IP_PRENORM.  Bit-identical to
+                                 dbsearch.py:303-304) is applied inside the call -- by the scan launch's own waves for a handful
+                                 of queries (ms_small_batch_thresholds: 4 by default), by one small preparation launch in front
+                                 of it otherwise -- then knn_exact_faiss as in MS_MODE_IP_PRENORM.  Bit-identical to
                                  ms_l2_normalize_rows_to + MS_MODE_IP_PRENORM */
 
 /* F.normalize(x) in place: x[r,:] /= max(||x[r,:]||_2, eps).  dbsearch.py:303-304 (eps 1e-12);

@@ -538,6 +538,11 @@ bool hist_take_clean(const void *ws, int64_t n, int nq, int k) {         // -> w
         if (e.ws == ws && e.n == n && e.nq == nq && e.k == k) { const bool c = e.clean; e.clean = false; return c; }
     return false;
 }
+void hist_invalidate(const void *ws) {          // a scan ran on this workspace outside the staged bookkeeping: its counters are dirty
+    std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
+    for (HistClean &e : g_hist_clean)
+        if (e.ws == ws) e.clean = false;
+}
 void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
     std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
     for (HistClean &e : g_hist_clean)
@@ -889,6 +894,12 @@ int ms_device_count(void) {
 
 int ms_device_cu_count(void) { return cu_count_cached(); }
 
+void ms_small_batch_thresholds(int *fused_merge_max_nq, int *inkernel_norm_max_nq) {
+    if (fused_merge_max_nq != nullptr) *fused_merge_max_nq = fused_merge_setting();
+    if (inkernel_norm_max_nq != nullptr) *inkernel_norm_max_nq = inkernel_norm_setting();
+}
+int ms_prefilter_max_k(void) { return MS_PREFILTER_MAX_K; }
+
 int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stream) {
     if (d != MS_DIM) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows: d must be %d (got %d)", MS_DIM, d);
     if (n < 0 || (n > 0 && x == nullptr)) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows: bad arguments");
@@ -1002,6 +1013,7 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
     uint32_t *ub_i = reinterpret_cast<uint32_t *>(ws + pl.off_ub_i);
     rc = run_prepass(pl, &sp, nq, ws, st);
     if (rc) return rc;
+    hist_invalidate(workspace);     // (a staged ms_ip_topk_scan on this workspace must not take the counters for clean afterwards)
     // ceil(k / 64) passes; pass p returns ranks [64p, 64p + kp) using the last entry of pass
     // p-1 as an exclusive upper bound in the total order.
     // a handful of queries, one pass: the scan launch merges its own lists (ms_scan_body, last workgroup of a query group)

@@ -13,10 +13,13 @@ import numpy as np
 DIM = 128
 CHUNK_ROWS = 1 << 20     # device-side DB generation granule (rows)
 
-# Empirical length distribution of the shipped TED slice (examples/database/ted100_9606_small:
-# min 25, median 97, mean 119.75, p95 267, max 683), summarised as
-# deciles so no data file is needed at run time.
-_TED_LEN_QUANTILES = np.array([25, 43, 56, 68, 81, 97, 113, 135, 166, 222, 683], dtype=np.float64)
+# Empirical length distribution of the shipped TED slice (examples/database/ted100_9606_small: min 25, median 97,
+# mean 119.75, p95 267, max 683): the histogram of its domain lengths, one count per length 0..683
+# (ted_length_hist.npy, 2.7 KB; the same array as tests/golden/ted_length_hist.npz).  E[N] = 119.75, E[N^2] = 20,506:
+# 1,000 domains drawn from it cost the encoder 10.9 TFLOP.
+_TED_LEN_QUANTILES = np.array([25, 43, 56, 68, 81, 97, 113, 135, 166, 222, 683], dtype=np.float64)      # (its deciles)
+_TED_HIST_FILE = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "ted_length_hist.npy")
+_ted_cdf = None
 
 
 def random_walk(n: int, seed: int, step: float = 3.8) -> np.ndarray:
@@ -28,7 +31,19 @@ def random_walk(n: int, seed: int, step: float = 3.8) -> np.ndarray:
 
 
 def ted_lengths(count: int, seed: int) -> np.ndarray:
-    """`count` domain lengths drawn from the TED-slice decile table (piecewise uniform)."""
+    """`count` domain lengths drawn from the length histogram of the shipped TED slice (inverse CDF)."""
+    global _ted_cdf
+    if _ted_cdf is None:
+        hist = np.load(_TED_HIST_FILE).astype(np.float64)
+        _ted_cdf = np.cumsum(hist) / hist.sum()
+    rng = np.random.default_rng(seed)
+    return np.maximum(1, np.searchsorted(_ted_cdf, rng.random(count), side="right")).astype(np.int32)
+
+
+def decile_lengths(count: int, seed: int) -> np.ndarray:
+    """`count` lengths drawn piecewise-uniformly from the slice's DECILES (top decile uniform on 222..683: E[N^2] = 33,205, a
+    heavier tail than the slice has).  Kept because the golden vectors of tests/golden were generated from inputs built with it
+    (raw_database / raw_queries); workloads that claim the TED distribution use ted_lengths."""
     rng = np.random.default_rng(seed)
     u = rng.random(count) * 10.0
     b = np.minimum(u.astype(np.int64), 9)
@@ -56,14 +71,14 @@ def raw_database(n: int, seed: int) -> Tuple[np.ndarray, np.ndarray]:
     """Un-normalised `.pt`-style database: (float32 [n,128] ~ N(0,1), lengths float32 [n])."""
     rng = np.random.default_rng(seed)
     db = rng.standard_normal((n, DIM)).astype(np.float32)
-    lengths = ted_lengths(n, seed + 7).astype(np.float32)
+    lengths = decile_lengths(n, seed + 7).astype(np.float32)
     return db, lengths
 
 
 def raw_queries(nq: int, seed: int) -> Tuple[np.ndarray, np.ndarray]:
     rng = np.random.default_rng(seed)
     q = rng.standard_normal((nq, DIM)).astype(np.float32)
-    qlen = ted_lengths(nq, seed + 7).astype(np.float32)
+    qlen = decile_lengths(nq, seed + 7).astype(np.float32)
     return q, qlen
 
 

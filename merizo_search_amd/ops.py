@@ -179,6 +179,14 @@ def pf_build_image(db, out=None):
     return img
 
 
+def small_batch_thresholds():
+    """(fused_merge_max_nq, inkernel_norm_max_nq) as the loaded library applies them (ms_small_batch_thresholds)."""
+    import ctypes
+    a, b = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.load().ms_small_batch_thresholds(ctypes.byref(a), ctypes.byref(b))
+    return int(a.value), int(b.value)
+
+
 def prefilter_serves(n: int, nq: int, k: int) -> bool:
     """The shapes ms_ip_topk_prefiltered serves itself (everything else it hands to ms_ip_topk): ONE statement of the rule for the
     engine, the bench and the tests (the library applies the same in pf_layout)."""

@@ -90,6 +90,15 @@ def test_c3_search_half_500k_raw_rows_1000_queries_cosine_mask(torch_gpu):
                          row_offset=a) for a, b in ((0, h), (h, n))]
     ms, mi = ops.topk_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
     assert torch.equal(mi, i) and torch.equal(ms, s)
+    # the product's path for this batch (foldclass/engine.py): rows normalised once, then the prefiltered search over their split
+    # image in MS_MODE_COSINE_UNIT == the fp32 scan on the same unit rows bit for bit, and == the reference arithmetic (oracle sample)
+    unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
+    kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=mincov)
+    su, iu = ops.ip_topk(unit, dq, k, **kw)
+    ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    sp, ip_ = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, workspace=ws, image=ops.pf_build_image(unit), **kw)
+    assert torch.equal(ip_, iu) and torch.equal(sp.view(torch.int32), su.view(torch.int32))
+    assert_topk_equivalent(sp.cpu().numpy()[sample], ip_.cpu().numpy()[sample], s_ref, i_ref, tol=COS_TOL)
 
 
 def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
@@ -133,6 +142,15 @@ def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
     s1, i1 = ops.ip_topk(db, q[:1], k, row_offset=lo)
     s32, i32 = ops.ip_topk(db, q[:32], k, row_offset=lo)
     assert torch.equal(i1, i[:1]) and torch.equal(s1, s[:1]) and torch.equal(i32, i[:32]) and torch.equal(s32, s[:32])
+    # the DEFAULT path of this shape in the driver: the prefiltered search over the split image of the shard (built once, +23.4 GB),
+    # and without an image (rows split in registers) -- indices and score bits of all 4096 lists == the fp32 scan's
+    del parts, ms, mi
+    ws = ops.PrefilterWorkspace(dev).get(n, nq, k)
+    img = ops.pf_build_image(db)
+    for image in (img, None):
+        sp, ip_ = ops.ip_topk_prefiltered(db, q, k, 1.0 + 1e-6, row_offset=lo, workspace=ws, image=image)
+        assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32))
+        assert ops.prefilter_flagged(ws) == 0
 
 def test_c1_real_size_cli_search_on_gpu(tmp_path, golden_dir):
     """C1 at its real size through the CLI on the HIP engine: M0 against the shipped TED example layout

@@ -161,7 +161,8 @@ def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, 
     kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=mincov)
     s0, i0 = ops.ip_topk(unit, dq, k, row_offset=7, **kw)
     s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, row_offset=7, workspace=ws, image=img, **kw)
-    assert ops.prefilter_flagged(ws) == 0
+    if mincov <= 1.0:           # (mincov 1.5 masks every row for the shortest queries: all-zero scores, no proof, exact pass)
+        assert ops.prefilter_flagged(ws) == 0
     assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
     sel = np.arange(0, nq, max(1, nq // 40))
     s_ref, i_ref = orc.cosine_topk(db, q[sel], k, lengths, qlen[sel], mincov, row_offset=7)

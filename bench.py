@@ -186,7 +186,8 @@ class SearchBench:
         """fp32 scan (ms_ip_topk stages) or, for the shapes it serves, the prefiltered search as the driver runs it on a resident
         shard: split image built once, the largest row norm measured once."""
         ops, dev = self.ops, self.db.device
-        self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_local, self.nq, self.k)
+        # (decided on the smallest shard so that every rank takes the same path: the steps contain collectives)
+        self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_total // self.world, self.nq, self.k)
         if self.prefilter and self.image is None:
             self.row_norm_bound = float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)
             self.image = ops.pf_build_image(self.db)

@@ -322,28 +322,25 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         const uint32_t dst = lds0 + (uint32_t)(((s & 1) * W_STAGE_F4 + pidx * 64) * sizeof(f32x4));
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff_w), "s"(base) : "memory", "m0");
     };
+    // The projections and distance weights of the next stage are BUFFER loads -- a scalar resource descriptor per (stage, k quad) and
+    // one 32-bit lane offset, as cheap to address as the asm form they replace (hipcc forms 64-bit lane addresses with a
+    // v_lshl_add_u64 per global_load) -- and, unlike asm loads, VISIBLE to the compiler: their destination registers are in flight
+    // across the compiler-scheduled matrix instructions of a stage, and a register the hardware fills behind the compiler's back
+    // is only safe as long as nothing makes hipcc move it (the scan lost a row that way in round 3: DESIGN.md 5.5).
     f32x4 pa[STAGE_G], pb[STAGE_G], pc[STAGE_G], hv[STAGE_G];
+    typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
     const uint32_t voff_a = (uint32_t)(((size_t)kh * p.total + gi) * sizeof(f32x4));
     const uint32_t voff_b = (uint32_t)(((size_t)kh * p.total + gj) * sizeof(f32x4));
     const uint32_t voff_c = (uint32_t)(kh * sizeof(f32x4));
-    auto load_a = [&](int s, int g) {
-        const uint64_t base = (uint64_t)(uintptr_t)p.ApT4 + (uint64_t)(2 * (STAGE_G * s + g)) * p.total * sizeof(f32x4);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pa[g]) : "v"(voff_a), "s"(base) : "memory");
+    auto buf_load = [&](const f32x4 *base, uint32_t voff) -> f32x4 {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00027000);
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, 0, 0));
     };
-    auto load_b = [&](int s, int g) {
-        const uint64_t base = (uint64_t)(uintptr_t)p.BpT4 + (uint64_t)(2 * (STAGE_G * s + g)) * p.total * sizeof(f32x4);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pb[g]) : "v"(voff_b), "s"(base) : "memory");
-    };
-    auto load_c = [&](int s, int g) {
-        const uint64_t base = (uint64_t)(uintptr_t)wc4 + (uint64_t)(2 * (STAGE_G * s + g)) * sizeof(f32x4);
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(pc[g]) : "v"(voff_c), "s"(base) : "memory");
-    };
-    auto wait_loads = [&]() {        // everything this wave has in flight: the next stage's operands and its W2 pieces
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(pa[0]), "+v"(pa[1]), "+v"(pa[2]), "+v"(pa[3]), "+v"(pa[4]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]), "+v"(pb[4]),
-                       "+v"(pc[0]), "+v"(pc[1]), "+v"(pc[2]), "+v"(pc[3]), "+v"(pc[4])
-                     :: "memory");
-    };
+    auto load_a = [&](int s, int g) { pa[g] = buf_load(p.ApT4 + (size_t)(2 * (STAGE_G * s + g)) * p.total, voff_a); };
+    auto load_b = [&](int s, int g) { pb[g] = buf_load(p.BpT4 + (size_t)(2 * (STAGE_G * s + g)) * p.total, voff_b); };
+    auto load_c = [&](int s, int g) { pc[g] = buf_load(wc4 + (size_t)(2 * (STAGE_G * s + g)), voff_c); };
+    // the W2 pieces of the next stage (LDS-DMA, inline asm: hipcc does not count them) have landed too
+    auto wait_loads = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 #pragma unroll
     for (int pc_ = 0; pc_ < 10; ++pc_) dma_w(0, pc_);
 #pragma unroll

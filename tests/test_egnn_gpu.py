@@ -105,3 +105,26 @@ def test_embedding_with_a_large_distance_weight_saturated_silu(case, golden_dir)
     assert np.isfinite(e).all()
     _check(e, g[f"emb_{case}"])
     _check(e, orc.egnn_embed(weights, pe, [coords])[0])
+
+
+def test_hundred_runs_of_a_ragged_batch_return_identical_bits(synthetic_weights):
+    """The encoder keeps loads in flight across compiler-scheduled matrix instructions (buffer loads the compiler can see, since
+    round 4; LDS-DMA pieces it cannot): 100 runs of one ragged batch -- 40 structures, 25..400 residues, two of them long enough
+    for several edge tiles per residue row -- must return the same bits, and two different batch compositions the same embeddings.
+    (The scan's lost-row bug of round 3 showed in one run of twenty and in no single-run parity test.)"""
+    import torch
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    weights, pe = synthetic_weights
+    enc = ops.EgnnEncoder(weights, pe, "cuda:0")
+    rng = np.random.default_rng(77)
+    lens = [int(x) for x in rng.integers(25, 160, size=38)] + [333, 400]
+    coords = [syn.random_walk(n, seed=500 + i) for i, n in enumerate(lens)]
+    first = enc.embed(coords).clone()
+    for run in range(100):
+        again = enc.embed(coords)
+        assert torch.equal(again.view(torch.int32), first.view(torch.int32)), "run %d differs" % run
+    perm = list(rng.permutation(len(coords)))
+    shuffled = enc.embed([coords[i] for i in perm])
+    assert torch.equal(shuffled.view(torch.int32), first[perm].view(torch.int32))
+

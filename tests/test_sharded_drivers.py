@@ -56,8 +56,9 @@ def _compare(work, world):
     assert np.array_equal(a["rows"], b["rows"]) and np.array_equal(a["scores"].view(np.uint32), b["scores"].view(np.uint32))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_run_dbsearch_sharded_equals_one_rank_gloo_oracle(world, tmp_path):
+    """(8 ranks: the node the north star names -- PackedExchange's strides and the merge of 8 gathered blocks through the drivers)"""
     work = str(tmp_path / "case")
     _make_case(work)
     _run_ranks(work, 1, "oracle")
@@ -174,6 +175,18 @@ def test_run_dbsearch_sharded_equals_one_rank_hip_engine_two_ranks(tmp_path):
 
 
 @pytest.mark.gpu
+def test_run_dbsearch_sharded_equals_one_rank_hip_engine_eight_ranks(tmp_path):
+    """The C4 / C5 rank count on the hardware there is: EIGHT child ranks sharing cuda:0 over gloo (MERIZO_SAME_DEVICE), the HIP
+    engine on every shard, one all-gather of 8 packed blocks, ms_topk_merge_strided at S = 8 -- == the one-rank run bit for bit
+    (resident, streamed, and the `.pt` cosine path; the prefiltered search across 8 ranks: test_bench_gpus_8_...)."""
+    work = str(tmp_path / "case")
+    _make_case(work, n=200_003, nq=70, k=10, batch=30_000)
+    _run_ranks(work, 1, "hip")
+    _run_ranks(work, 8, "hip")
+    _compare(work, 8)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,nq,k,world", [(3, 1, 2, 2), (1, 2, 1, 2), (5, 3, 5, 3)])
 def test_run_dbsearch_sharded_tiny_databases_hip_engine(n, nq, k, world, tmp_path):
     """Shards smaller than k, and ranks with no rows at all (more ranks than rows): padded / empty per-shard lists go
@@ -254,3 +267,21 @@ def test_bench_gpus_2_self_launches_and_is_exact(tmp_path):
     assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 300000
     assert line["recall_at_k"] == 1.0 and line["planted_recall"] == 1.0
     assert line["topk_identical_to_torch_bruteforce"].startswith("96 of 96")
+    assert line["prefiltered"]["identical_to_fp32"] is True
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_self_launches_on_tiny_shards(tmp_path):
+    """`python bench.py --gpus 8` (the driver's scaling run) end to end on one GPU: eight ranks on cuda:0 over gloo, 100,000 rows
+    each; exact, and the prefiltered block of the same step identical to the fp32 scan across the 8-way exchange."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MS_BENCH_SAME_DEVICE="1", MS_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--rows", "800000", "--nq", "96", "--steps", "2",
+                        "--warmup", "1", "--no-extras", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["rows_per_gpu"] == 100000
+    assert line["recall_at_k"] == 1.0 and line["planted_recall"] == 1.0
+    assert line["topk_identical_to_torch_bruteforce"].startswith("96 of 96")
+    assert line["prefiltered"]["identical_to_fp32"] is True

@@ -1,4 +1,4 @@
-"""One prefiltered search shape in a loop (for rocprofv3): python3 tools/pf_loop.py ROWS NQ K [ITERS]"""
+"""One prefiltered search shape in a loop (for rocprofv3): python3 tools/pf_loop.py ROWS NQ K [ITERS] [noimage]"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,10 +7,12 @@ from merizo_search_amd.foldclass import synthetic as syn
 n, nq, k = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 d = syn.device_database(n, 0, 0, "cuda:0", normalize=True)
+img = None if "noimage" in sys.argv else ops.pf_build_image(d)
 q_raw = torch.randn(nq, 128, device="cuda") * 3
 ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
 out = (torch.empty(nq, k, device="cuda"), torch.empty(nq, k, dtype=torch.int64, device="cuda"))
-for _ in range(3 if n > 20_000_000 else 30): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
+kw = dict(mode=ops.MODE_IP_NORMQ, workspace=ws, out=out, image=img)
+for _ in range(3 if n > 20_000_000 else 30): ops.ip_topk_prefiltered(d, q_raw, k, 1.0 + 1e-6, **kw)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(iters): ops.ip_topk_prefiltered(d, q_raw, k, 1.0, mode=ops.MODE_IP_NORMQ, workspace=ws, out=out)
-torch.cuda.synchronize(); print(f"n={n} nq={nq} k={k}: {(time.perf_counter()-t0)/iters*1e3:.4f} ms per search, fell back: {ops.prefilter_fell_back(ws)}")
+for _ in range(iters): ops.ip_topk_prefiltered(d, q_raw, k, 1.0 + 1e-6, **kw)
+torch.cuda.synchronize(); print(f"n={n} nq={nq} k={k}: {(time.perf_counter()-t0)/iters*1e3:.4f} ms per search, exact-pass queries: {ops.prefilter_flagged(ws)}")

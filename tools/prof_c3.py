@@ -1,5 +1,5 @@
 """The bench's c3_search workload for profiling (500,000 unit rows, 1000 queries, cosine + length mask, top-10):
-python tools/prof_c3.py [reps]"""
+python tools/prof_c3.py [reps] [prefiltered]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,6 +16,12 @@ unit = ops.l2_normalize_rows_(db.clone(), 1e-8)
 ws = ops.TopKWorkspace(dev).get(n, nq, k)
 out_s = torch.empty((nq, k), dtype=torch.float32, device=dev); out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
 kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov)
-for _ in range(reps):
-    ops.ip_topk_prepare(unit, q, k, ws, **kw); ops.ip_topk_scan(unit, q, k, ws, **kw); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
+if "prefiltered" in sys.argv:
+    img = ops.pf_build_image(unit)
+    pws = ops.PrefilterWorkspace(dev).get(n, nq, k)
+    for _ in range(reps):
+        ops.ip_topk_prefiltered(unit, q, k, 1.0 + 1e-5, workspace=pws, image=img, out=(out_s, out_i), **kw)
+else:
+    for _ in range(reps):
+        ops.ip_topk_prepare(unit, q, k, ws, **kw); ops.ip_topk_scan(unit, q, k, ws, **kw); ops.ip_topk_finish(n, nq, k, ws, out_s, out_i)
 torch.cuda.synchronize()

@@ -23,6 +23,7 @@
 #include "ms_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -66,8 +67,26 @@ constexpr int P_WN1T = P_BG + 4;                   // [384 k][256 o]
 constexpr int P_BN1 = P_WN1T + NIN * NHID;         // [256]
 constexpr int P_WN2T = P_BN1 + NHID;               // [256 k][128 o]
 constexpr int P_BN2 = P_WN2T + NHID * DIM;         // [128]
-constexpr int P_LAYER = P_BN2 + DIM;
-static_assert(P_LAYER % 4 == 0 && P_W2F % 4 == 0 && P_WC % 4 == 0 && P_B1 % 4 == 0, "float4 alignment");
+constexpr int P_W2S = P_BN2 + DIM;                 // [33 blocks][8 nt][3 parts][64 lanes][8 bf16]: W2 split into bf16 hi / mid / lo,
+constexpr int KB16 = 33;                           //   in B-fragment order of v_mfma_f32_32x32x16_bf16 (K = 514 padded to 528)
+constexpr int W2S_BLOCK_BYTES = 8 * 3 * 64 * 16;   // 24 KiB per k block of 16
+constexpr int P_LAYER = P_W2S + KB16 * W2S_BLOCK_BYTES / 4;
+static_assert(P_LAYER % 4 == 0 && P_W2F % 4 == 0 && P_WC % 4 == 0 && P_B1 % 4 == 0 && P_W2S % 4 == 0, "float4 alignment");
+
+// x = hi + mid + lo EXACTLY, each part a bf16 (the upper 16 bits of what is left: 8 + 8 + 8 significant bits).  A product x * w
+// over the parts has nine terms; hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid are kept -- what is dropped (mid.lo, lo.mid,
+// lo.lo) is below 2^-23 |x w|, the size of one fp32 rounding.  bf16 x bf16 products are exact in the fp32 accumulator.
+typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4_e __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
+    const uint32_t a = __float_as_uint(x0), b = __float_as_uint(x1);
+    hi = __builtin_amdgcn_perm(b, a, 0x07060302u);                  // upper halves of x1 : x0
+    const float r0 = x0 - __uint_as_float(a & 0xFFFF0000u), r1 = x1 - __uint_as_float(b & 0xFFFF0000u);
+    const uint32_t c = __float_as_uint(r0), d = __float_as_uint(r1);
+    mid = __builtin_amdgcn_perm(d, c, 0x07060302u);
+    const float s0 = r0 - __uint_as_float(c & 0xFFFF0000u), s1 = r1 - __uint_as_float(d & 0xFFFF0000u);
+    lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
 
 __device__ __forceinline__ float silu_f(float x) {
     // x / (1 + exp(-x)); v_exp_f32 + v_rcp_f32 (about 1 ulp each)
@@ -98,7 +117,7 @@ __global__ __launch_bounds__(256) void ms_egnn_prepare_kernel(const float *__res
     const int layer = blockIdx.y;
     const float *w = blob + (size_t)layer * LAYER_FLOATS;
     float *p = prep + (size_t)layer * P_LAYER;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P_LAYER; t += gridDim.x * blockDim.x) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < P_W2S; t += gridDim.x * blockDim.x) {
         float v = 0.0f;
         if (t < P_W1BT) {                       // W1aT[k][c] = W1[c][k]
             const int k = t / EHP, c = t % EHP;
@@ -135,6 +154,22 @@ __global__ __launch_bounds__(256) void ms_egnn_prepare_kernel(const float *__res
             v = w[C_BN2 + (t - P_BN2)];
         }
         p[t] = v;
+    }
+    // W2S[b][nt][part][lane = 32 h + n][j]: part of W2[32 nt + n][16 b + 8 h + j]; one thread per (b, nt, lane): 8 values -> 3 x 16 bytes
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < KB16 * 8 * 64; t += gridDim.x * blockDim.x) {
+        const int lane = t & 63, nt = (t >> 6) & 7, b = t >> 9;
+        const int n = 32 * nt + (lane & 31), k0 = 16 * b + 8 * (lane >> 5);
+        u32x4_e hi, mid, lo;
+#pragma unroll
+        for (int jp = 0; jp < 4; ++jp) {
+            const int ka = k0 + 2 * jp, kb = ka + 1;
+            const float x0 = ka < EH ? w[C_W2 + n * EH + ka] : 0.0f, x1 = kb < EH ? w[C_W2 + n * EH + kb] : 0.0f;
+            uint32_t h_, m_, l_;
+            split3_pair(x0, x1, h_, m_, l_);
+            hi[jp] = h_; mid[jp] = m_; lo[jp] = l_;
+        }
+        u32x4_e *dst = reinterpret_cast<u32x4_e *>(p + P_W2S) + ((size_t)(b * 8 + nt) * 3) * 64 + lane;
+        dst[0] = hi; dst[64] = mid; dst[128] = lo;
     }
 }
 
@@ -286,7 +321,16 @@ struct EdgeParams {
 // cluster behind the stage's 160 MFMAs, kept there by a scheduling fence (hipcc would spread it through the MFMAs).
 constexpr int W_STAGE_F4 = STAGE_G * 8 * 64;                      // float4 per W2 stage (40 KiB)
 constexpr int EDGE_LDS = 2 * W_STAGE_F4 * 16;                     // two ring slots: 80 KiB per workgroup, two workgroups per CU
+constexpr int EDGE_LDS_SPLIT = 3 * W2S_BLOCK_BYTES;               // split form: three slots of one k block (24 KiB) each: 72 KiB
 
+// SPLIT (round 4): the same GEMM on the bf16 matrix instruction -- v_mfma_f32_32x32x16_bf16 at 16 x the rate of the fp32 one --
+// with both operands split three ways (split3_pair): per 16 k and 32 channels SIX matrix instructions (hi.hi, hi.mid, mid.hi,
+// hi.lo, lo.hi, mid.mid) of 32 cycles instead of eight fp32 ones of 64: 0.375 of the matrix time, fp32-grade results (what is
+// dropped is below one fp32 rounding per product; accumulation is fp32 either way).  W2 is split once (ms_egnn_prepare_weights: the
+// image P_W2S, in B-fragment order, 24 KiB per k block, streamed through a ring of three slots by LDS-DMA); H is split by the lane
+// that computes it (~45 vector instructions per 8 values, in the shadow of the 48 matrix instructions of a k block: next to the
+// bf16 matrix instruction vector instructions are NOT additive).  One barrier per k block.
+template <bool SPLIT>
 __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *Wring = reinterpret_cast<f32x4 *>(smem);                 // [2 slots][5 g][8 nt][64 lanes]
@@ -322,6 +366,29 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         const uint32_t dst = lds0 + (uint32_t)(((s & 1) * W_STAGE_F4 + pidx * 64) * sizeof(f32x4));
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff_w), "s"(base) : "memory", "m0");
     };
+    float d2;
+    {
+        // rel_coors, dist = norm(rel), then dist * dist: my_egnn_nocoords.py:48-49,58
+        const float dx = p.coords[3 * gi] - p.coords[3 * gj];
+        const float dy = p.coords[3 * gi + 1] - p.coords[3 * gj + 1];
+        const float dz = p.coords[3 * gi + 2] - p.coords[3 * gj + 2];
+        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
+        d2 = dist * dist;
+    }
+    f32x16 acc[8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+#ifdef MS_STAMP
+    unsigned long long tH = 0, tB1 = 0, tM = 0, tB2 = 0, tc = __builtin_amdgcn_s_memtime();
+    const unsigned long long t_begin = tc;
+#define EST(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tc; tc = n_; }
+#else
+#define EST(acc)
+#endif
+    if constexpr (!SPLIT) {
     // The projections and distance weights of the next stage are BUFFER loads -- a scalar resource descriptor per (stage, k quad) and
     // one 32-bit lane offset, as cheap to address as the asm form they replace (hipcc forms 64-bit lane addresses with a
     // v_lshl_add_u64 per global_load) -- and, unlike asm loads, VISIBLE to the compiler: their destination registers are in flight
@@ -345,15 +412,6 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
     for (int pc_ = 0; pc_ < 10; ++pc_) dma_w(0, pc_);
 #pragma unroll
     for (int g = 0; g < STAGE_G; ++g) { load_a(0, g); load_b(0, g); load_c(0, g); }
-    float d2;
-    {
-        // rel_coors, dist = norm(rel), then dist * dist: my_egnn_nocoords.py:48-49,58
-        const float dx = p.coords[3 * gi] - p.coords[3 * gj];
-        const float dy = p.coords[3 * gi + 1] - p.coords[3 * gj + 1];
-        const float dz = p.coords[3 * gi + 2] - p.coords[3 * gj + 2];
-        const float dist = sqrtf(dx * dx + dy * dy + dz * dz);
-        d2 = dist * dist;
-    }
     wait_loads();
     // H = SiLU(Ap_i + Bp_j + w_c * d2) of one stage, straight into the A-fragment registers
     auto compute_h = [&]() {
@@ -369,19 +427,6 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
     };
     compute_h();
 
-    f32x16 acc[8];
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
-
-#ifdef MS_STAMP
-    unsigned long long tH = 0, tB1 = 0, tM = 0, tB2 = 0, tc = __builtin_amdgcn_s_memtime();
-    const unsigned long long t_begin = tc;
-#define EST(acc) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); acc += n_ - tc; tc = n_; }
-#else
-#define EST(acc)
-#endif
     for (int s = 0; s < NSTAGE; ++s) {
         // W2 stage s has landed for every wave (its pieces were issued a stage ago), and every wave is done reading the other slot
         __syncthreads();
@@ -412,6 +457,89 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         if (more) { wait_loads(); compute_h(); }        // (issued ~150 MFMAs ago: landed long since)
         __builtin_amdgcn_sched_barrier(0);
         EST(tH)
+    }
+    } else {
+        // ---------------- split-bf16 form ----------------
+        const u32x4_e *Sring = reinterpret_cast<const u32x4_e *>(smem);      // [3 slots][8 nt][3 parts][64 lanes] of 16 bytes
+        const u32x4_e *w2s = reinterpret_cast<const u32x4_e *>(p.prep + P_W2S);
+        constexpr int BLK_V = 8 * 3 * 64;                                    // 16-byte vectors per k block
+        auto dma_s = [&](int b, int piece) {                                 // pieces 6 w .. 6 w + 5 (1 KiB each) of block b -> slot b % 3
+            const int pidx = wave * 6 + piece;
+            const uint64_t base = (uint64_t)(uintptr_t)w2s + ((uint64_t)b * BLK_V + (uint64_t)pidx * 64) * 16;
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((b % 3) * BLK_V + pidx * 64) * 16));
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff_w), "s"(base) : "memory", "m0");
+        };
+        // lane (r, h) owns edge row 32 w + r and the k half h of every block: k = 16 b + 8 h + j = quads 4 b + 2 h, 4 b + 2 h + 1.
+        // The last block's upper half (k = 520 .. 527) has no projections: it reads the lower half's (W2S is zero there).
+        const uint32_t total16 = (uint32_t)p.total * 16u;
+        const uint32_t va = (uint32_t)(((size_t)(2 * kh) * p.total + gi) * 16), vb = (uint32_t)(((size_t)(2 * kh) * p.total + gj) * 16);
+        const uint32_t va0 = (uint32_t)((size_t)gi * 16), vb0 = (uint32_t)((size_t)gj * 16), vc = (uint32_t)(2 * kh * 16);
+        auto buf_load2 = [&](const f32x4 *base, uint32_t voff, uint32_t soff) -> f32x4 {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, 0x7fffffff, 0x00027000);
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0));
+        };
+        f32x4 ld[6];
+        auto load6 = [&](int b) {
+            const bool last = b == KB16 - 1;
+            const f32x4 *ba = p.ApT4 + (size_t)(4 * b) * p.total, *bb = p.BpT4 + (size_t)(4 * b) * p.total, *bc = wc4 + 4 * b;
+            ld[0] = buf_load2(ba, last ? va0 : va, 0); ld[1] = buf_load2(ba, last ? va0 : va, total16);
+            ld[2] = buf_load2(bb, last ? vb0 : vb, 0); ld[3] = buf_load2(bb, last ? vb0 : vb, total16);
+            ld[4] = buf_load2(bc, last ? 0u : vc, 0);  ld[5] = buf_load2(bc, last ? 0u : vc, 16);
+        };
+        // H = SiLU(Ap_i + Bp_j + w_c d2) of this lane's 8 k values, split into the three A operands
+        auto make_a = [&](bf16x8_e &ah, bf16x8_e &am, bf16x8_e &al) {
+            u32x4_e hi, mid, lo;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 zsum = ld[half] + ld[2 + half];
+                const f32x2 d2v = {d2, d2};
+                const f32x2 z01 = __builtin_elementwise_fma(f32x2{ld[4 + half].x, ld[4 + half].y}, d2v, f32x2{zsum.x, zsum.y});
+                const f32x2 z23 = __builtin_elementwise_fma(f32x2{ld[4 + half].z, ld[4 + half].w}, d2v, f32x2{zsum.z, zsum.w});
+                const f32x2 h01 = silu2_f(z01), h23 = silu2_f(z23);
+                uint32_t h_, m_, l_;
+                split3_pair(h01.x, h01.y, h_, m_, l_); hi[2 * half] = h_; mid[2 * half] = m_; lo[2 * half] = l_;
+                split3_pair(h23.x, h23.y, h_, m_, l_); hi[2 * half + 1] = h_; mid[2 * half + 1] = m_; lo[2 * half + 1] = l_;
+            }
+            ah = __builtin_bit_cast(bf16x8_e, hi); am = __builtin_bit_cast(bf16x8_e, mid); al = __builtin_bit_cast(bf16x8_e, lo);
+        };
+#pragma unroll
+        for (int pc_ = 0; pc_ < 6; ++pc_) dma_s(0, pc_);
+#pragma unroll
+        for (int pc_ = 0; pc_ < 6; ++pc_) dma_s(1, pc_);
+        load6(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        bf16x8_e ah, am, al, nh, nm, nl;
+        make_a(ah, am, al);
+        nh = ah; nm = am; nl = al;
+        load6(1);
+        for (int b = 0; b < KB16; ++b) {
+            // W2S block b has landed for every wave (each waited for its own pieces in the middle of the last iteration), and every
+            // wave is done reading slot (b - 1) % 3, which block b + 2 is about to overwrite
+            __syncthreads();
+            EST(tB1)
+            const u32x4_e *Sl = Sring + (b % 3) * BLK_V + lane;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                const bf16x8_e bh = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 0) * 64]), bm = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 1) * 64]),
+                               bl = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 2) * 64]);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[nt], 0, 0, 0);
+                if (nt == 3 && b + 1 < KB16) {
+                    // the next block's projections were requested a block ago; everything older than that -- this wave's pieces of
+                    // W2S block b + 1 -- has landed with them (vector-memory operations complete in order)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    make_a(nh, nm, nl);
+                }
+                if (nt >= 5 && b + 2 < KB16) { dma_s(b + 2, 2 * (nt - 5)); dma_s(b + 2, 2 * (nt - 5) + 1); }
+                if (nt == 7 && b + 2 < KB16) load6(b + 2);
+            }
+            EST(tM)
+            ah = nh; am = nm; al = nl;
+        }
     }
 #ifdef MS_STAMP
     const unsigned long long t_loop_end = tc;
@@ -731,9 +859,15 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
     hipLaunchKernelGGL(ms_egnn_init_nodes_kernel, dim3((unsigned)((total + 7) / 8)), dim3(256), 0, st, offsets, nb,
                        (int)total, pe, node_dom, h0);
     MS_LAUNCH_CHECK("ms_egnn_init_nodes_kernel");
-    const size_t edge_lds = (size_t)EDGE_LDS;
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
+    // the edge GEMM: split-bf16 matrix instructions (default; fp32-grade results) or MS_EGNN_SPLIT=0: the fp32 ones
+    static const int split_form = [] { const char *e = getenv("MS_EGNN_SPLIT"); return e ? atoi(e) : 1; }();
+    const size_t edge_lds = split_form ? (size_t)EDGE_LDS_SPLIT : (size_t)EDGE_LDS;
+    if (split_form)
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel<true>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
+    else
+        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel<false>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));
     float *hin = h0, *hout = h1;
     for (int layer = 0; layer < 2; ++layer) {
         const float *lp = prep + (size_t)layer * P_LAYER;
@@ -748,7 +882,8 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
 #ifdef MS_STAMP
         ep.stamps = ms_egnn_stamp_buffer();
 #endif
-        hipLaunchKernelGGL(ms_egnn_edge_kernel, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
+        if (split_form) hipLaunchKernelGGL(ms_egnn_edge_kernel<true>, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
+        else hipLaunchKernelGGL(ms_egnn_edge_kernel<false>, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
         MS_LAUNCH_CHECK("ms_egnn_edge_kernel");
         NodeParams np;
         np.prep = lp; np.h_in = hin; np.part = part; np.offsets = offsets; np.rec_pre = rec_pre; np.node_dom = node_dom;

@@ -12,6 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 EGNN_REL = 1e-5
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -127,4 +128,30 @@ def test_hundred_runs_of_a_ragged_batch_return_identical_bits(synthetic_weights)
     perm = list(rng.permutation(len(coords)))
     shuffled = enc.embed([coords[i] for i in perm])
     assert torch.equal(shuffled.view(torch.int32), first[perm].view(torch.int32))
+
+
+def test_fp32_edge_gemm_form_still_matches_the_goldens_and_the_split_form(encoder, golden_dir, tmp_path):
+    """MS_EGNN_SPLIT=0 selects the fp32 matrix instructions for the edge GEMM (the form of rounds 1-3; the split-bf16 form is the
+    default since round 4).  A fresh process (the switch is read once) embeds the golden structures with it: same parity bar against
+    the reference goldens, and within 2e-6 (relative to max |e|) of the split form of this process."""
+    import subprocess
+    import sys
+    g = np.load(os.path.join(golden_dir, "egnn.npz"))
+    out = tmp_path / "fp32_form.npy"
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from merizo_search_amd import ops\n"
+        "from merizo_search_amd.foldclass import weights as W\n"
+        "g = np.load(%r)\n"
+        "w, pe = W.pack_state_dict(W.synthetic_state_dict(0))\n"
+        "enc = ops.EgnnEncoder(w, pe, 'cuda:0')\n"
+        "np.save(%r, enc.embed([g['coords_' + c] for c in %r]).cpu().numpy())\n"
+    ) % (REPO, os.path.join(REPO, "tests"), os.path.join(golden_dir, "egnn.npz"), str(out), list(CASES))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, MS_EGNN_SPLIT="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fp32 = np.load(out)
+    split = encoder.embed([g[f"coords_{c}"] for c in CASES]).cpu().numpy()
+    for idx, c in enumerate(CASES):
+        _check(fp32[idx], g[f"emb_{c}"])
+        assert np.abs(fp32[idx] - split[idx]).max() <= 2e-6 * np.abs(split[idx]).max()
 

@@ -211,6 +211,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         return;
     }
 
+#ifdef MS_PF2_PRIO
+    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (experiment: static priority for the younger half)
+#endif
     // ---- compute waves: queries, lists, bounds
     ScanState<SAMPLE ? 1 : KL> st;
     ScanHist hg;

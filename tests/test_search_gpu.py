@@ -12,6 +12,7 @@ from conftest import assert_topk_equivalent
 
 pytestmark = pytest.mark.gpu
 COS_TOL = 2e-6
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -615,3 +616,32 @@ def test_repeated_searches_return_identical_results(k, torch_gpu):
     for _ in range(150):
         s, i = ops.ip_topk(d, dq, k)
         assert torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32))
+
+
+def test_few_query_shapes_with_the_production_thresholds(tmp_path):
+    """tests/conftest.py widens the few-query shortcuts (MS_FUSED_MERGE_MAX_NQ = 8, MS_INKERNEL_NORM_MAX_NQ = 16) so that the parity
+    cases run through them; THIS test runs 1..20 raw queries with the library's own defaults (2 and 4: what a user gets) in a fresh
+    process -- the switches are read once -- against the oracle: indices and score bits identical."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+from oracle import oracle as orc
+assert ops.small_batch_thresholds() == (2, 4), ops.small_batch_thresholds()
+db = syn.normalized_database(150_003, seed=881)
+d = torch.from_numpy(db).cuda()
+for nq in (1, 2, 3, 4, 5, 8, 9, 16, 17, 20):
+    q, _ = syn.raw_queries(nq, seed=882 + nq)
+    dq = torch.from_numpy(q).cuda()
+    s, i = ops.ip_topk(d, dq, 10, mode=ops.MODE_IP_NORMQ, row_offset=5)
+    qn = ops.l2_normalize_rows(dq, 1e-12).cpu().numpy()
+    s_ref, i_ref = orc.ip_topk(db, qn, 10, row_offset=5, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32)), nq
+print("production thresholds ok")
+'''
+    env = {k: v for k, v in os.environ.items() if k not in ("MS_FUSED_MERGE_MAX_NQ", "MS_INKERNEL_NORM_MAX_NQ")}
+    r = subprocess.run([sys.executable, "-c", code, REPO], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "production thresholds ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -24,7 +24,7 @@ tojson $OUT/r04_pf_c4_pmc.json "ms_scan_pf2_kernel<10, 8, false>" "tools/pf_loop
 kt pf_c3 $R/tools/prof_c3.py 20 prefiltered
 pmc pf_c3_busy "$BUSY" $R/tools/prof_c3.py 5 prefiltered
 pmc pf_c3_fetch FETCH_SIZE $R/tools/prof_c3.py 5 prefiltered
-tojson $OUT/r04_pf_c3_pmc.json "ms_scan_pf2_kernel<5, 8, false>" "tools/prof_c3.py 5 prefiltered (c3_search: 500,000 unit rows + lengths, 1000 queries, mincov 0.7, top-10)" 258000000 128000000000 /tmp/pmc_pf_c3_fetch /tmp/pmc_pf_c3_busy
+tojson $OUT/r04_pf_c3_pmc.json "ms_scan_pf2_kernel<10, 8, false>" "tools/prof_c3.py 5 prefiltered (c3_search: 500,000 unit rows + lengths, 1000 queries, mincov 0.7, top-10)" 258000000 128000000000 /tmp/pmc_pf_c3_fetch /tmp/pmc_pf_c3_busy
 rm -f $OUT/pmc_*.log
 ls $OUT
 for f in $OUT/*_pmc.json; do echo $f; grep -E "traffic_over|matrix_pipe" $f; done

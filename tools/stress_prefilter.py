@@ -1,5 +1,6 @@
 """Randomised parity sweep of the prefiltered search against the fp32 scan on the GPU (both through the C ABI; the fp32 scan is
-the one pinned to the oracle): larger shapes than the oracle sweep can afford, plain / clustered / rescaled databases.
+the one pinned to the oracle): larger shapes than the oracle sweep can afford, plain / clustered / rescaled databases, inner
+product and cosine-on-unit-rows with a length mask, over the split image and without one.
 usage: python tools/stress_prefilter.py SEED CASES"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -7,7 +8,7 @@ import numpy as np, torch
 from merizo_search_amd import ops
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-bad = fell = 0
+bad = fell = flagged_total = queries_total = 0
 t0 = time.time()
 g = torch.Generator(device="cuda")
 for c in range(ncases):
@@ -35,14 +36,22 @@ for c in range(ncases):
     if not raw:
         q = q / q.norm(dim=1, keepdim=True)
     off = int(rng.integers(0, 1 << 33))
-    s0, i0 = ops.ip_topk(db, q, k, mode=mode, row_offset=off)
+    use_image = bool(rng.integers(0, 4))                       # three in four over the split image
+    kw = {}
+    if use_image and kind != 3 and rng.integers(0, 3) == 0:    # cosine on unit rows + length mask (needs the image)
+        mode, bound = ops.MODE_COSINE_UNIT, 1.0 + 1e-5
+        db = ops.l2_normalize_rows_(db, 1e-8)
+        kw = dict(lengths=torch.randint(40, 400, (n,), generator=g, device="cuda").float(),
+                  qlen=torch.randint(40, 400, (nq,), generator=g, device="cuda").float(), mincov=float(rng.choice([0.0, 0.7])))
+    img = ops.pf_build_image(db) if use_image else None
+    s0, i0 = ops.ip_topk(db, q, k, mode=mode, row_offset=off, **kw)
     ws = ops.PrefilterWorkspace(db.device).get(n, nq, k)
-    s1, i1 = ops.ip_topk_prefiltered(db, q, k, bound, mode=mode, row_offset=off, workspace=ws)
-    fb = ops.prefilter_fell_back(ws)
-    fell += int(fb)
+    s1, i1 = ops.ip_topk_prefiltered(db, q, k, bound, mode=mode, row_offset=off, workspace=ws, image=img, **kw)
+    fl = ops.prefilter_flagged(ws)
+    fell += int(fl > 0); flagged_total += fl; queries_total += nq
     if not (torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))):
         bad += 1
-        print("MISMATCH", dict(n=n, nq=nq, k=k, kind=kind, raw=raw, fell_back=fb))
-    del db, q, ws
-print(f"{ncases} cases, {bad} mismatches, exact pass needed in {fell}, {time.time() - t0:.1f} s")
+        print("MISMATCH", dict(n=n, nq=nq, k=k, kind=kind, raw=raw, mode=mode, image=use_image, flagged=fl))
+    del db, q, ws, img
+print(f"{ncases} cases, {bad} mismatches, exact pass needed in {fell} cases for {flagged_total} of {queries_total} queries, {time.time() - t0:.1f} s")
 sys.exit(1 if bad else 0)

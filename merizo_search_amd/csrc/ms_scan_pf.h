@@ -17,10 +17,10 @@
 // hides everything that is not a matrix instruction -- synchronisation, filters, the rare path: a wave alone on its SIMD issues
 // every instruction at ~5 cycles with the matrix pipe idle meanwhile (first version of this kernel, 4 waves x 2 query tiles:
 // 2,670 cycles per tile for 1,536 of matrix work even with the rare path compiled out; stamps in DESIGN.md).
-// No barrier inside the scan: the waves synchronise through 2 NW counters in LDS -- landed[w] = tiles whose pieces from wave w
-// have arrived, consumed[w] = tiles wave w has pulled into registers -- each wave publishes its own two during a stage and
-// looks at a snapshot of all of them taken during the previous stage's chain; a wave may run W - 1 tiles ahead of the slowest one
-// before it waits for its pieces, and R - D before the slowest one's slot holds it up.
+// No barrier inside the scan: the waves synchronise through one ARRIVAL COUNTER per tile in LDS (16 of them, reused modulo 16): a
+// wave whose pieces of tile t + W have landed (a counted vector-memory wait, D - W stages after it issued them) adds one to that
+// tile's counter; a wave starts stage t when the counter of tile t + 1 shows NW arrivals per use -- one ds_read_b32 taken during the
+// previous stage's chain, one scalar compare.  A wave may run W - 1 tiles ahead of the slowest one.
 //
 // The rare path is NOT the loader-wave kernel's.  A visit only APPENDS: a lane whose score passes its threshold counts it in the
 // shared bound's histogram and stores (score, row) into a buffer of its own in LDS (PF2_CAND entries; ~150 instructions per
@@ -63,8 +63,11 @@ constexpr int PF2_OFF_AUX = PF2_R * 16384;
 constexpr int PF2_OFF_HIST = PF2_OFF_AUX + PF2_AUXR * 256;      // the shared bound's counters of a wave's 32 queries, staged by LDS-DMA: 2 KiB; waves
                                                                 // w and w + 4 take turns at area w & 3 (half a period apart)
 constexpr int PF2_OFF_CAND = PF2_OFF_HIST + 4 * 2048;           // [wave][slot][lane] (score, row): 512 B per slot
-constexpr int PF2_OFF_CNT = PF2_OFF_CAND + 8 * PF2_CAND * 512;  // landed[8]
-constexpr int PF2_LDS = PF2_OFF_CNT + 64;
+constexpr int PF2_ARR = 16;                                     // arrival counters: one per tile modulo 16, counting up by NW per reuse
+constexpr int PF2_OFF_CNT = PF2_OFF_CAND + 8 * PF2_CAND * 512;  // arrived[16]
+constexpr int PF2_OFF_DUMMY = PF2_OFF_CNT + 64;                 // cosine mode: where the waves other than 0 drop their (unused) aux piece
+constexpr int PF2_LDS = PF2_OFF_DUMMY + 7 * 256;
+static_assert(PF2_ARR > PF2_R + PF2_W, "a counter is not reused while anybody may still wait for its previous tile");
 static_assert(PF2_LDS <= 160 * 1024, "LDS of one CU");
 static_assert(MS_HIST_PERIOD >= 16, "eight waves take turns at four staging areas: phases 2 w and 2 w + 2 of a period");
 
@@ -82,7 +85,8 @@ __device__ __forceinline__ void ms_pf2_vmcnt() {        // (inline asm: the comp
 
 // The approximate score of (row, query): ONE accumulator chain, k blocks in order, per block hi.qhi, hi.qlo, lo.qhi.  The sample
 // pass and the full pass run exactly this sequence (the sample's bound must hold bit for bit).
-template <int KL, int NW, bool SAMPLE>
+// MASK: MS_MODE_COSINE_UNIT with a length mask (p.lengths != NULL).
+template <int KL, int NW, bool SAMPLE, bool MASK>
 __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const ScanParams p) {
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
     constexpr int PPW = 16 / NW;                       // LDS-DMA pieces of a tile per wave
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    lds_flag_t *landed = (lds_flag_t *)((lds_char_t *)smem + PF2_OFF_CNT);      // [8]
+    lds_flag_t *arrived = (lds_flag_t *)((lds_char_t *)smem + PF2_OFF_CNT);     // [16]
     const float *auxring = reinterpret_cast<const float *>(smem + PF2_OFF_AUX);
 
     const int bid = blockIdx.x;
@@ -109,19 +113,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     const int nfull = (int)((row_end - row_begin) >> 5);
     const int rem = (int)((row_end - row_begin) & 31);
     const int ntl = SAMPLE ? (nfull < p.max_tiles ? nfull : p.max_tiles) : nfull + (rem > 0 ? 1 : 0);
-    const bool mask_on = p.lengths != nullptr;          // cosine on unit rows (uniform)
+    constexpr bool mask_on = MASK;                      // cosine on unit rows
 
     // query tile of wave w: qg * NW + w; a wave without a real one only loads its pieces of the tiles
     const int qtile = qg * NW + wave;
     const bool has_q = qtile < p.n_qtiles;
-    if (tid < 8) landed[tid] = tid >= NW ? 0xFFFFFFFFu : 0u;           // (waves that do not exist have loaded everything)
+    if (tid < PF2_ARR) arrived[tid] = 0u;
     __syncthreads();
     const uint32_t ring_lds = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(lds_char_t *)smem);
 
     // ---- this wave's pieces of tile t -> slot t % R (wave 0, cosine mode: one more, the rows' lengths)
     const uint32_t voff = (uint32_t)(16 * lane);
     const uint64_t img0 = (uint64_t)(uintptr_t)p.pf_image + (uint64_t)(row_begin >> 5) * 16384u + (uint32_t)(1024 * PPW) * (uint32_t)wave;
-    const bool aux_wave = mask_on && wave == 0;
+    // (cosine mode: EVERY wave issues one more piece per tile so that the counted waits are the same for all of them; only wave 0's
+    //  -- the rows' lengths -- is read)
     uint64_t it_sb = 0;            // base address and LDS destination of the tile being issued (uniform)
     uint32_t it_dst = 0;
     auto issue_prep = [&](int t) __attribute__((always_inline)) {
@@ -141,10 +146,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         }
     };
     auto issue_aux = [&](int t) __attribute__((always_inline)) {
-        if (aux_wave) {
+        if constexpr (MASK) {
             int64_t row = row_begin + (int64_t)t * 32 + r;
             if (row >= p.n) row = p.n - 1;
-            ms_glds_v4((uint32_t)__builtin_amdgcn_readfirstlane(ring_lds + PF2_OFF_AUX + (uint32_t)(t % PF2_AUXR) * 256u), p.lengths + row);
+            const uint32_t dst = wave == 0 ? ring_lds + PF2_OFF_AUX + (uint32_t)(t % PF2_AUXR) * 256u
+                                           : ring_lds + PF2_OFF_DUMMY + (uint32_t)(wave - 1) * 256u;
+            ms_glds_v4((uint32_t)__builtin_amdgcn_readfirstlane(dst), p.lengths + row);
         }
     };
     auto issue_tile = [&](int t) __attribute__((always_inline)) {
@@ -156,36 +163,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     // own pieces of every tile but the youngest N issued have landed
     auto wait_own = [&](auto n_c) __attribute__((always_inline)) {
         constexpr int N = decltype(n_c)::value;
-        if (aux_wave) ms_pf2_vmcnt<(PPW + 1) * N>(); else ms_pf2_vmcnt<PPW * N>();
+        ms_pf2_vmcnt<(PPW + (MASK ? 1 : 0)) * N>();
     };
-    // the tail of a stream: `tiles` = how many of the youngest tiles issued may still be in flight
-    auto wait_own_tail = [&](int tiles) __attribute__((always_inline)) {
-        if (tiles <= 0) ms_pf2_vmcnt<0>();
-        else if (tiles == 1) wait_own(std::integral_constant<int, 1>{});
-        else if (tiles == 2) wait_own(std::integral_constant<int, 2>{});
-        else if (tiles == 3) wait_own(std::integral_constant<int, 3>{});
-        else wait_own(std::integral_constant<int, 4>{});
+    // publication: this wave's pieces of tile t have landed -> one more arrival at the tile's counter
+    const uint32_t arr_lds = ring_lds + PF2_OFF_CNT;
+    auto publish = [&](int t) __attribute__((always_inline)) {
+        if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(arrived + (t & (PF2_ARR - 1))), 1u, __ATOMIC_RELAXED,
+                                              __HIP_MEMORY_SCOPE_WORKGROUP);
     };
-    static_assert(PF2_D - 2 <= 4, "wait_own_tail lists the cases 0 .. 4");
-
-    ms_u32x4 seenL0 = {0, 0, 0, 0}, seenL1 = seenL0;       // the counters as this wave last read them
-    auto read_counters = [&]() __attribute__((always_inline)) {
-        seenL0 = *(lds_flag4_t *)landed; seenL1 = *((lds_flag4_t *)landed + 1);
-    };
-    auto min8 = [](const ms_u32x4 &a, const ms_u32x4 &b) __attribute__((always_inline)) -> uint32_t {
-        const uint32_t m0 = a.x < a.y ? a.x : a.y, m1 = a.z < a.w ? a.z : a.w, m2 = b.x < b.y ? b.x : b.y, m3 = b.z < b.w ? b.z : b.w;
-        const uint32_t m01 = m0 < m1 ? m0 : m1, m23 = m2 < m3 ? m2 : m3;
-        return (uint32_t)__builtin_amdgcn_readfirstlane(m01 < m23 ? m01 : m23);
-    };
-    auto wait_landed = [&](uint32_t need) __attribute__((always_inline)) {
+    // every wave's pieces of tile t have landed: its counter has been raised NW times per use of it
+    uint32_t seen = 0;                                  // the counter of the tile the next stage needs, as last read
+    auto read_arrived = [&](int t) __attribute__((always_inline)) { seen = arrived[t & (PF2_ARR - 1)]; };
+    auto wait_arrived = [&](int t) __attribute__((always_inline)) {
+        const uint32_t need = (uint32_t)NW * (uint32_t)(t / PF2_ARR + 1);
 #pragma unroll 1
-        for (uint32_t spins = 0; min8(seenL0, seenL1) < need; ++spins) {
+        for (uint32_t spins = 0; (uint32_t)__builtin_amdgcn_readfirstlane(seen) < need; ++spins) {
             if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
             __builtin_amdgcn_s_sleep(1);
-            read_counters();
+            read_arrived(t);
         }
     };
-
+    (void)arr_lds;
     // ---- prologue: the first D tiles are requested before anything else (HBM latency overlaps the query set-up)
 #pragma unroll
     for (int t = 0; t < PF2_D; ++t)
@@ -193,27 +191,26 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
 
     if (!has_q) {
         // loading-only wave (the workgroup's last query tiles are padding): issue, publish, keep pace with the readers
-        // (its own entry in landed[] counts too: it paces itself exactly like a wave that computes)
+        // (it waits for the same arrivals as a wave that computes: that is what keeps it from overwriting a slot in use)
         if (ntl > 0) {
-            if (ntl >= PF2_D) wait_own(std::integral_constant<int, PF2_D - 2>{}); else ms_pf2_vmcnt<0>();
-            if (lane == 0) landed[wave] = (uint32_t)((ntl < 2) ? ntl : 2);
+            if (ntl >= PF2_D) wait_own(std::integral_constant<int, PF2_D - PF2_W>{}); else ms_pf2_vmcnt<0>();
+#pragma unroll
+            for (int t = 0; t < PF2_W; ++t)
+                if (t < ntl) publish(t);
         }
         for (int t = 0; t < ntl; ++t) {
-            if (t + 1 < ntl) { read_counters(); wait_landed((uint32_t)(t + 2)); }
+            if (t + 1 < ntl) { read_arrived(t + 1); wait_arrived(t + 1); }
             if (t + PF2_D < ntl) {
                 issue_tile(t + PF2_D);
                 wait_own(std::integral_constant<int, PF2_D - PF2_W>{});   // own pieces of tiles <= t + W have landed
             } else {
-                wait_own_tail(ntl - 1 - PF2_W - t);
+                ms_pf2_vmcnt<0>();
             }
-            if (lane == 0) landed[wave] = (uint32_t)((t + PF2_W + 1 < ntl) ? t + PF2_W + 1 : ntl);
+            if (t + PF2_W < ntl) publish(t + PF2_W);
         }
         return;
     }
 
-#ifdef MS_PF2_PRIO
-    if (NW == 8 && wave >= 4) __builtin_amdgcn_s_setprio(1);       // (experiment: static priority for the younger half)
-#endif
     // ---- compute waves: queries, lists, bounds
     ScanState<SAMPLE ? 1 : KL> st;
     ScanHist hg;
@@ -339,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         PF2_T0();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PF2_ACC(sp_lgkm)
-        if (STEADY || t + 1 < ntl) wait_landed((uint32_t)(t + 2));          // tile t + 1 has landed from every wave
+        if (STEADY || t + 1 < ntl) wait_arrived(t + 1);                   // tile t + 1 has landed from every wave
         PF2_ACC(sp_sync)
 #pragma unroll
         for (int i = 0; i < 16; ++i) out[i] = 0.0f;
@@ -361,25 +358,25 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         MS_PF2_BLOCK(0)
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(1)
-        if (issuing) issue_prep(t + PF2_D);                     // (slot (t + D) % R is free: see the ring geometry)
+        if (STEADY || issuing) issue_prep(t + PF2_D);           // (slot (t + D) % R is free: see the ring geometry)
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(2)
-        if (issuing) issue_piece(std::integral_constant<int, 0>{});
+        if (STEADY || issuing) issue_piece(std::integral_constant<int, 0>{});
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(3)
-        if (issuing) issue_piece(std::integral_constant<int, 1>{});
+        if (STEADY || issuing) issue_piece(std::integral_constant<int, 1>{});
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(4)
-        if (issuing) issue_piece(std::integral_constant<int, 2>{});
+        if (STEADY || issuing) issue_piece(std::integral_constant<int, 2>{});
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(5)
-        if (issuing) { issue_piece(std::integral_constant<int, 3>{}); issue_aux(t + PF2_D); }
+        if (STEADY || issuing) { issue_piece(std::integral_constant<int, 3>{}); issue_aux(t + PF2_D); }
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(6)
-        // own pieces of tiles <= t + W have landed (issued D - W stages ago): published for the other waves
-        if (STEADY || issuing) wait_own(std::integral_constant<int, PF2_D - PF2_W>{}); else wait_own_tail(ntl - 1 - PF2_W - t);
-        if (lane == 0) landed[wave] = (uint32_t)((STEADY || t + PF2_W + 1 < ntl) ? t + PF2_W + 1 : ntl);
-        read_counters();                                        // for the next stage (the other waves published during their chains)
+        // own pieces of tile t + W have landed (issued D - W stages ago; the tail of a stream drains): one more arrival for that tile
+        if (STEADY || issuing) wait_own(std::integral_constant<int, PF2_D - PF2_W>{}); else ms_pf2_vmcnt<0>();
+        if (STEADY || t + PF2_W < ntl) publish(t + PF2_W);
+        read_arrived(t + 2);                                    // for the next stage (the other waves publish during their chains)
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(7)
 #undef MS_PF2_BLOCK
@@ -417,16 +414,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     const unsigned long long sp_c0 = __builtin_amdgcn_s_memtime(), sp_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (ntl > 0) {
-        // tiles 0 and 1: own pieces, then (tile 0) everybody's.  With fewer than D tiles fewer pieces were issued: drain.
-        if (ntl >= PF2_D) wait_own(std::integral_constant<int, PF2_D - 2>{}); else ms_pf2_vmcnt<0>();
-        if (lane == 0) landed[wave] = (uint32_t)((ntl < 2) ? ntl : 2);
-        read_counters();
-        wait_landed(1u);
+        // the first W tiles: own pieces, then (tile 0) everybody's.  With fewer than D tiles fewer pieces were issued: drain.
+        if (ntl >= PF2_D) wait_own(std::integral_constant<int, PF2_D - PF2_W>{}); else ms_pf2_vmcnt<0>();
+#pragma unroll
+        for (int t = 0; t < PF2_W; ++t)
+            if (t < ntl) publish(t);
+        read_arrived(0);
+        wait_arrived(0);
         {
             const f32x4 *src = frag_base(0);
 #pragma unroll
             for (int f = 0; f < 16; ++f) fr[f] = src[64 * f];
         }
+        read_arrived(1);
         // Shared bound, every MS_HIST_PERIOD tiles: the 16 bucket counters of this wave's 32 queries are fetched by LDS-DMA (sc1:
         // past this CU's L1) -- no destination register, nothing the compiler has to wait for; the counted vector-memory waits of
         // the stages cover them -- and read back one iteration later: the highest bucket edge with at least k rows at or above
@@ -467,10 +467,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
             }
         };
         int t = 0;
+        // the body of a stream: every stage issues (t + 1 + D < ntl), two tiles per iteration ...
+        for (; t + 1 + PF2_D < ntl; t += 2) {
+            if (hist_on) hist_step(t);
+            stage(std::true_type{}, t, accA, accB);             // accA = scores of tile t - 1 (or -inf), accB <- tile t
+            stage(std::true_type{}, t + 1, accB, accA);         // accB = tile t, accA <- tile t + 1
+        }
+        // ... and its last D + 1 tiles, with the tests in
         for (; t + 1 < ntl; t += 2) {
             if (hist_on) hist_step(t);
-            stage(std::false_type{}, t, accA, accB);            // accA = scores of tile t - 1 (or -inf), accB <- tile t
-            stage(std::false_type{}, t + 1, accB, accA);        // accB = tile t, accA <- tile t + 1
+            stage(std::false_type{}, t, accA, accB);
+            stage(std::false_type{}, t + 1, accB, accA);
         }
         if (t < ntl) {
             stage(std::false_type{}, t, accA, accB);
@@ -524,11 +531,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     }
 }
 
-template <int KL, int NW>
+template <int KL, int NW, bool MASK>
 int launch_scan_pf2(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_pf2_kernel<KL, NW, false>),
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_pf2_kernel<KL, NW, false, MASK>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF2_LDS));
-    hipLaunchKernelGGL((ms_scan_pf2_kernel<KL, NW, false>), dim3(pl.grid), dim3(64 * NW), PF2_LDS, st, sp);
+    hipLaunchKernelGGL((ms_scan_pf2_kernel<KL, NW, false, MASK>), dim3(pl.grid), dim3(64 * NW), PF2_LDS, st, sp);
     MS_LAUNCH_CHECK("ms_scan_pf2_kernel");
     return MS_OK;
 }

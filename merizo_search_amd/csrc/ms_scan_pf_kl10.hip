@@ -2,5 +2,6 @@
 #include "ms_scan_pf.h"
 
 int ms_launch_scan_pf2_kl10(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    return sp.qpw == 2 ? launch_scan_pf2<10, 8>(pl, sp, st) : launch_scan_pf2<10, 4>(pl, sp, st);
+    if (sp.lengths != nullptr) return sp.qpw == 2 ? launch_scan_pf2<10, 8, true>(pl, sp, st) : launch_scan_pf2<10, 4, true>(pl, sp, st);
+    return sp.qpw == 2 ? launch_scan_pf2<10, 8, false>(pl, sp, st) : launch_scan_pf2<10, 4, false>(pl, sp, st);
 }

@@ -3,5 +3,5 @@
 
 int ms_launch_scan_pf2_kl32(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
     // (32-entry lists do not fit 256 registers: four waves, one per SIMD)
-    return launch_scan_pf2<32, 4>(pl, sp, st);
+    return sp.lengths != nullptr ? launch_scan_pf2<32, 4, true>(pl, sp, st) : launch_scan_pf2<32, 4, false>(pl, sp, st);
 }

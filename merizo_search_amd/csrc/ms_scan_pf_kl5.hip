@@ -2,21 +2,22 @@
 #include "ms_scan_pf.h"
 
 int ms_launch_scan_pf2_kl5(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    return sp.qpw == 2 ? launch_scan_pf2<5, 8>(pl, sp, st) : launch_scan_pf2<5, 4>(pl, sp, st);
+    if (sp.lengths != nullptr) return sp.qpw == 2 ? launch_scan_pf2<5, 8, true>(pl, sp, st) : launch_scan_pf2<5, 4, true>(pl, sp, st);
+    return sp.qpw == 2 ? launch_scan_pf2<5, 8, false>(pl, sp, st) : launch_scan_pf2<5, 4, false>(pl, sp, st);
+}
+
+template <int NW, bool MASK>
+static int launch_sample_pf2(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
+    MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_pf2_kernel<5, NW, true, MASK>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF2_LDS));
+    hipLaunchKernelGGL((ms_scan_pf2_kernel<5, NW, true, MASK>), dim3(pl.grid), dim3(64 * NW), PF2_LDS, st, sp);
+    MS_LAUNCH_CHECK("ms_scan_pf2_kernel (sample)");
+    return MS_OK;
 }
 
 int ms_launch_sample_pf2(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    if (sp.qpw == 2) {
-        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_pf2_kernel<5, 8, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF2_LDS));
-        hipLaunchKernelGGL((ms_scan_pf2_kernel<5, 8, true>), dim3(pl.grid), dim3(512), PF2_LDS, st, sp);
-    } else {
-        MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_pf2_kernel<5, 4, true>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)PF2_LDS));
-        hipLaunchKernelGGL((ms_scan_pf2_kernel<5, 4, true>), dim3(pl.grid), dim3(256), PF2_LDS, st, sp);
-    }
-    MS_LAUNCH_CHECK("ms_scan_pf2_kernel (sample)");
-    return MS_OK;
+    if (sp.lengths != nullptr) return sp.qpw == 2 ? launch_sample_pf2<8, true>(pl, sp, st) : launch_sample_pf2<4, true>(pl, sp, st);
+    return sp.qpw == 2 ? launch_sample_pf2<8, false>(pl, sp, st) : launch_sample_pf2<4, false>(pl, sp, st);
 }
 
 // ---- the image itself: one wave per tile; lane (r, h) reads its half row (256 B) and writes sixteen 16-byte fragments, each

@@ -11,7 +11,7 @@
 // ------------------------------------------------------------------ scan kernel --------
 // The decomposition of one scan launch: query tiles x row streams.  Computed on the host for an ordinary search (make_plan) and ON
 // THE DEVICE for the exact pass behind a prefiltered search, whose batch -- the queries whose proof failed -- is only known there
-// (ms_compact_flagged_kernel writes a ScanDevPlan, the gated scan and merge read it).
+// (the last workgroup of ms_rescore_kernel writes a ScanDevPlan, the gated scan and merge read it).
 struct ScanDevPlan {
     int nq, nq_pad, n_qtiles, qwb, n_qgroups, n_sgroups, n_streams, rows_per_stream, P, grid;
     int pad_[6];

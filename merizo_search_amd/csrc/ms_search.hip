@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
-                                                             const ScanDevPlan *dp, const int *qmap) {
+                                                             const ScanDevPlan *dp, const int *qmap, int sparse) {
     if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int q = blockIdx.x;
@@ -227,6 +227,62 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
     const int tid = threadIdx.x, kP = k * P;
     uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
     const size_t base = (size_t)q * kP;
+    if (sparse) {
+        // SPARSE lists (the prefilter's: 256 streams, 20 slots each, ~100 entries in all -- a bound filtered the rest): every thread
+        // walks its own list (four ranks in one round trip, further ones only where the fourth is occupied) and appends what it finds
+        // to a pool; the pool ranks itself (rows are distinct: an entry's place = how many beat it).  40 KB of mostly empty slots
+        // are not staged at all: 28 -> ~5 us at C2.  More than 512 entries (clustered data): the general merge below.
+        __shared__ int pool_n;
+        unsigned long long *pk = reinterpret_cast<unsigned long long *>(smem);            // [512]  (the scratch area: 8 KiB)
+        uint2 *pe = reinterpret_cast<uint2 *>(smem + 4096);                                // [512]
+        if (tid == 0) pool_n = 0;
+        __syncthreads();
+        for (int l = tid; l < P; l += 256) {
+            float s4[4];
+            uint32_t i4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                i4[r] = MS_IDX_NONE; s4[r] = -INFINITY;
+                if (r < k) { s4[r] = part_s[base + (size_t)r * P + l]; i4[r] = part_i[base + (size_t)r * P + l]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (i4[r] == MS_IDX_NONE) continue;
+                const int pos = atomicAdd(&pool_n, 1);
+                if (pos < 512) { const uint2 e = make_uint2(__float_as_uint(s4[r]), i4[r]); pk[pos] = ms_order_key(e); pe[pos] = e; }
+            }
+            if (k > 4 && i4[3] != MS_IDX_NONE) {
+                for (int r = 4; r < k; ++r) {
+                    const uint32_t ii = part_i[base + (size_t)r * P + l];
+                    if (ii == MS_IDX_NONE) break;
+                    const int pos = atomicAdd(&pool_n, 1);
+                    if (pos < 512) { const uint2 e = make_uint2(__float_as_uint(part_s[base + (size_t)r * P + l]), ii); pk[pos] = ms_order_key(e); pe[pos] = e; }
+                }
+            }
+        }
+        __syncthreads();
+        const int n = pool_n;
+        if (n <= 512) {
+            for (int e = tid; e < n; e += 256) {
+                const unsigned long long key = pk[e];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) rank += pk[j] > key ? 1 : 0;
+                if (rank < k) {
+                    const uint2 v = pe[e];
+                    const size_t o = (size_t)q_out * out_stride + out_col0 + rank;
+                    out_s[o] = __uint_as_float(v.x);
+                    out_i[o] = row_offset + (int64_t)v.y;
+                }
+            }
+            if (tid < k && tid >= n) {
+                const size_t o = (size_t)q_out * out_stride + out_col0 + tid;
+                out_s[o] = -INFINITY;
+                out_i[o] = -1;
+            }
+            return;
+        }
+        __syncthreads();            // (the pool is abandoned: the scratch area is the general merge's from here on)
+    }
     if ((kP & 3) == 0) {
         const float4 *ps4 = reinterpret_cast<const float4 *>(part_s + base);
         const uint4 *pi4 = reinterpret_cast<const uint4 *>(part_i + base);
@@ -318,10 +374,24 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 // approximate score), hence s <= a_last + E; if the k-th best exact score is above that, no other row can be in the
 // answer or tie with it (the candidate list must be full for that argument: a list with empty slots raises the gate too).  Otherwise (near-ties by the dozen around the k-th best) the query raises the gate and the exact
 // pipeline, queued behind this kernel, runs after all.
+// The flagged queries are gathered for the exact pass right here (round 4b; a separate one-workgroup kernel before): a flagged
+// query takes the next slot of the compacted batch (an atomic counter in library-owned memory: the order of the batch varies from
+// run to run, the results do not -- every query's exact pass is its own) and copies its vector, bound and length there; the LAST
+// workgroup to finish (a ticket) writes the launch plan of the exact pass for that many queries, raises the gate and resets both
+// counters.
+struct PfCompact {
+    float *qn_c, *lb_c, *qlen_c;
+    int *qmap;
+    ScanDevPlan *dp;
+    uint32_t *gate;          // [0] gate, [1] epoch, [2] flagged count (diagnostics), [4] slot counter, [5] ticket
+    uint32_t epoch;
+    int64_t n;
+    int cus, nq;
+};
 __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
                                                         const int64_t *ai, int64_t row_offset, float err_coef, const float *lengths,
                                                         const float *qlen, float mincov, float *out_s, int64_t *out_i, uint32_t *flag,
-                                                        float *exact_lb) {
+                                                        float *exact_lb, const PfCompact cp) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -369,57 +439,43 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     if (lane < k && lane >= nvalid) { out_s[o0 + lane] = -INFINITY; out_i[o0 + lane] = -1; }
     if (row >= 0 && rank == k - 1) kth = s;
     __syncthreads();
+    __shared__ int slot_s;
     if (lane == 0) {
         exact_lb[q] = kth;      // k rows score at least this: the bound the exact scan starts from, should it have to run (-inf: none)
         // (a list that is not full cannot happen on a database of >= 65,536 rows unless rows were lost to a bound: no proof then either)
-        flag[q] = (!full || !(kth > a_last + err_coef * qnorm)) ? 1u : 0u;
-    }
-}
-
-// The queries whose proof failed, gathered into a dense batch for the exact pass: their prepared query vectors, their lower
-// bounds (the k-th best exact score among their candidates) and query lengths, the map back to their rows of the outputs, and
-// the launch decomposition of an exact scan over exactly that many queries (ms_plan_core, the host's own arithmetic).  One
-// workgroup; the gate word is set to this call's epoch when there is anything to do (the gated launches return at once otherwise).
-__global__ __launch_bounds__(256) void ms_compact_flagged_kernel(const uint32_t *flag, int nq, int64_t n, int cus, const float *qn,
-                                                                 const float *exact_lb, const float *qlen, float *qn_c, float *lb_c,
-                                                                 float *qlen_c, int *qmap, ScanDevPlan *dp, uint32_t *gate, uint32_t epoch) {
-    __shared__ int wave_cnt[4];
-    __shared__ int base;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int q0 = 0; q0 < nq; q0 += 256) {
-        const int q = q0 + tid;
-        const bool f = q < nq && flag[q] != 0u;
-        const unsigned long long bal = __ballot(f);
-        const int before = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_cnt[wave] = __popcll(bal);
-        __syncthreads();
-        int off = base;
-        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
-        if (f) {
-            const int j = off + before;
-            qmap[j] = q;
-            lb_c[j] = exact_lb[q];
-            qlen_c[j] = qlen != nullptr ? qlen[q] : 0.0f;
+        const bool flagged = !full || !(kth > a_last + err_coef * qnorm);
+        flag[q] = flagged ? 1u : 0u;
+        int slot = -1;
+        if (flagged) {
+            slot = (int)atomicAdd(cp.gate + 4, 1u);
+            cp.qmap[slot] = q;
+            cp.lb_c[slot] = kth;
+            cp.qlen_c[slot] = qlen != nullptr ? qlen[q] : 0.0f;
         }
-        __syncthreads();
-        if (tid == 0) base += wave_cnt[0] + wave_cnt[1] + wave_cnt[2] + wave_cnt[3];
-        __syncthreads();
+        slot_s = slot;
     }
-    const int cnt = base;
-    for (int e = tid; e < cnt * (MS_DIM / 4); e += 256) {
-        const int j = e / (MS_DIM / 4), c = e % (MS_DIM / 4);
-        reinterpret_cast<float4 *>(qn_c)[(size_t)j * (MS_DIM / 4) + c] = reinterpret_cast<const float4 *>(qn)[(size_t)qmap[j] * (MS_DIM / 4) + c];
+    __syncthreads();
+    const int slot = slot_s;
+    if (slot >= 0) {
+        cp.qn_c[(size_t)slot * MS_DIM + lane] = qs[lane];
+        cp.qn_c[(size_t)slot * MS_DIM + 64 + lane] = qs[64 + lane];
     }
-    if (tid == 0) {
-        ScanDevPlan d;
-        ms_plan_core(n, cnt > 0 ? cnt : 1, cus, &d);
-        if (cnt == 0) { d.nq = 0; d.grid = 0; }
-        *dp = d;
-        gate[0] = cnt > 0 ? epoch : 0u;
-        gate[1] = epoch;                 // (diagnostics: the epoch of the last prefiltered search on this workspace, and how many
-        gate[2] = (uint32_t)cnt;         //  of its queries needed the exact pass)
+    if (lane == 0) {
+        __threadfence();                                         // (this workgroup's slot is taken before its ticket)
+        const uint32_t done = atomicAdd(cp.gate + 5, 1u);
+        if (done == (uint32_t)cp.nq - 1u) {                     // the last workgroup: every flagged query has its slot
+            __threadfence();
+            const int cnt = (int)atomicAdd(cp.gate + 4, 0u);
+            ScanDevPlan d;
+            ms_plan_core(cp.n, cnt > 0 ? cnt : 1, cp.cus, &d);
+            if (cnt == 0) { d.nq = 0; d.grid = 0; }
+            *cp.dp = d;
+            cp.gate[0] = cnt > 0 ? cp.epoch : 0u;
+            cp.gate[1] = cp.epoch;
+            cp.gate[2] = (uint32_t)cnt;
+            cp.gate[4] = 0u;                                     // (for the next call on this workspace: stream order)
+            cp.gate[5] = 0u;
+        }
     }
 }
 
@@ -721,7 +777,7 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 // plan (pl.P is then its upper bound), query q of the compacted batch is output row qmap[q]
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st,
-                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr) {
+                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0) {
     const uint32_t *gate = sp.gate;
     const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
@@ -732,7 +788,7 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
@@ -1154,7 +1210,7 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
         if (out_scores == nullptr || out_idx == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: NULL outputs");
         float *as = reinterpret_cast<float *>(ws + L.off_as);
         int64_t *ai = reinterpret_cast<int64_t *>(ws + L.off_ai);
-        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st);
+        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1);     // (sparse lists)
         if (rc) return rc;
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
         const uint32_t epoch = next_epoch();
@@ -1165,12 +1221,12 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
         float *qlen_c = reinterpret_cast<float *>(ws + L.off_qlen_c);
         int *qmap = reinterpret_cast<int *>(ws + L.off_qmap);
         ScanDevPlan *dp = reinterpret_cast<ScanDevPlan *>(ws + L.off_dp);
+        PfCompact cp;
+        cp.qn_c = qn_c; cp.lb_c = lb_c; cp.qlen_c = qlen_c; cp.qmap = qmap; cp.dp = dp; cp.gate = gate; cp.epoch = epoch; cp.n = n;
+        cp.cus = cu_count_cached(); cp.nq = nq;
         hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, MS_PF_ERR * row_norm_bound,
-                           lengths, qlen, mincov, out_scores, out_idx, flag, exact_lb);
+                           lengths, qlen, mincov, out_scores, out_idx, flag, exact_lb, cp);
         MS_LAUNCH_CHECK("ms_rescore_kernel");
-        hipLaunchKernelGGL(ms_compact_flagged_kernel, dim3(1), dim3(256), 0, st, flag, nq, n, cu_count_cached(), sp.qn, exact_lb, qlen, qn_c, lb_c,
-                           qlen_c, qmap, dp, gate, epoch);
-        MS_LAUNCH_CHECK("ms_compact_flagged_kernel");
         // The exact pass, for the flagged queries ONLY (the reference's semantics are per query: dbsearch.py:234-242): an fp32 scan
         // and a merge over the compacted batch, decomposed on the device (ScanDevPlan), both returning at once when no query was
         // flagged.  No sample pass: the k-th best exact score among a query's candidates is already a lower bound on its k-th

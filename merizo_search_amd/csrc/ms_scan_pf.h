@@ -182,6 +182,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
             __builtin_amdgcn_s_sleep(1);
             read_arrived(t);
         }
+        asm volatile("" ::: "memory");          // (the tile's fragment reads stay behind the wait)
     };
     (void)arr_lds;
     // ---- prologue: the first D tiles are requested before anything else (HBM latency overlaps the query set-up)

@@ -322,6 +322,35 @@ __device__ __forceinline__ void ms_lane_insert(ScanState<KL> &st, float v, uint3
     st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
 }
 
+// The same step when BOTH lanes of a pair already hold the pair's next candidate (cand, crow) -- the append-and-flush rare path of
+// the fp32 scan (ms_scan_loader_kernel, lists of 16 / 32 entries per lane) feeds a query's buffered candidates in ascending row order,
+// so "new rows lose ties" holds exactly as in ms_row_insert and the lists come out the same, entry for entry.
+typedef uint32_t ms_u32x2 __attribute__((ext_vector_type(2)));
+template <int KL>
+__device__ __forceinline__ void ms_pair_insert(ScanState<KL> &st, float cand, uint32_t crow, int h) {
+    const float c = (cand > st.tau) ? cand : -INFINITY;
+    const float pl_s = ms_xor32_f(st.ls[KL - 1], h);
+    const uint32_t pl_i = ms_xor32_u(st.li[KL - 1], h);
+    const bool spill = (h == 1) && (c > pl_s);
+    const float x_cmp = spill ? __builtin_nanf("") : c;
+    const float ins_s = spill ? pl_s : c;
+    const uint32_t ins_i = spill ? pl_i : crow;
+    bool ge_hi = st.ls[KL - 1] >= x_cmp;
+#pragma unroll
+    for (int e = KL - 1; e >= 1; --e) {
+        const bool ge_lo = st.ls[e - 1] >= x_cmp;
+        const float ns = ge_lo ? ins_s : st.ls[e - 1];
+        const uint32_t ni = ge_lo ? ins_i : st.li[e - 1];
+        st.ls[e] = ge_hi ? st.ls[e] : ns;
+        st.li[e] = ge_hi ? st.li[e] : ni;
+        ge_hi = ge_lo;
+    }
+    st.ls[0] = ge_hi ? st.ls[0] : ins_s;
+    st.li[0] = ge_hi ? st.li[0] : ins_i;
+    const float worst = ms_xor32_f(st.ls[KL - 1], h);   // lane q+32's last = the pair's k-th best
+    st.tau = fmaxf(h ? st.ls[KL - 1] : worst, st.floor);
+}
+
 // insertion steps for one 32-row tile whose (scaled, masked) scores are sc[16]; rows in ascending
 // order: row 8 g + 4 hh + j lives in lanes of half hh, register 4 g + j
 #ifndef MS_STATIC_INSERT_MAX_KL
@@ -948,6 +977,13 @@ constexpr int LDR_D = MS_LDR_D;  // tiles the loader keeps in flight before publ
 constexpr int LDR_AUX = 2 * LDR_R;   // aux (row scale / length) ring: a tile's aux data is read up to two stages after its slot was
                                      // released, while the loader may run LDR_R - 1 tiles ahead of the slowest wave
 constexpr int LDR_LDS = LDR_R * 16384 + LDR_AUX * 256 + 64;
+// Append-and-flush rare path (lists of 16 / 32 entries per lane, k > 20): candidate buffers, LDR_CAND entries of 8 bytes per lane
+// and compute wave, behind the counters
+#ifndef MS_APPEND_MIN_KL
+#define MS_APPEND_MIN_KL 32
+#endif
+constexpr int LDR_CAND = 8;
+constexpr int LDR_LDS_APPEND = LDR_LDS + 4 * LDR_CAND * 512;
 
 // LDS-DMA pieces as inline asm; each statement overwrites M0 and declares it as a clobber:
 // 64 lanes x 16 B (or 4 B) from global memory to LDS bytes lds_addr + lane * size.  M0 is a reserved
@@ -1260,6 +1296,86 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     float smax = -INFINITY;                                                 // SAMPLE: this lane's best score so far
     bool neg_tau = AUXM == 2 && (__ballot(st.tau < 0.0f) != 0);             // unit rows: some query of this wave still has a negative threshold
     uint32_t landed_seen = 0;                                               // the loader's counter as this wave last saw it (scalar)
+    // Rare path of a tile whose lane maximum passed: the candidates go into the lists.
+    //   lists of 5 / 10 entries per lane: one sorted-insertion step per database ROW that holds a candidate (ms_tile_insert);
+    //   lists of 32 (APPEND): such a step costs 3,300 cycles per visit there (stamps: 24 % of the tiles at k = 64), so a lane whose score passes only counts it in the shared bound's histogram and APPENDS (score, row) to a
+    //   buffer of its own in LDS; when some lane holds more than LDR_CAND - 4 entries (checked once per group of four score
+    //   registers), and at the end of the stream, the buffers are emptied: per round every query takes the candidate with the
+    //   smaller row of its two lanes' buffer heads (rows ascend within a buffer: a two-way merge, so ties still go to the lower
+    //   row) and ONE insertion step serves all 32 queries (ms_pair_insert).  Thresholds move at flushes and with the shared bound.
+    constexpr bool APPEND = KL >= MS_APPEND_MIN_KL && !SAMPLE && !PF;
+    typedef __attribute__((address_space(3))) ms_u32x2 lds_cand_t;
+    uint32_t ccnt = 0;
+#ifdef MS_STAMP_FLUSH
+    unsigned long long stamp_flush = 0, stamp_nflush = 0, stamp_rounds = 0;
+#endif
+    auto cand_slot = [&](uint32_t c) __attribute__((always_inline)) -> lds_cand_t * {
+        return (lds_cand_t *)((__attribute__((address_space(3))) char *)smem + LDR_LDS + (wave * LDR_CAND) * 512) + c * 64 + lane;
+    };
+    auto flush = [&]() __attribute__((always_inline)) {
+        uint32_t head = 0;
+#ifdef MS_STAMP_FLUSH
+        const unsigned long long f0_ = __builtin_amdgcn_s_memtime();
+        stamp_nflush += 1;
+#endif
+#pragma unroll 1
+        while (__ballot(head < ccnt) != 0) {
+#ifdef MS_STAMP_FLUSH
+            stamp_rounds += 1;
+#endif
+            const bool have = head < ccnt;
+            const ms_u32x2 e = *cand_slot(have ? head : 0);
+            const float v = have ? __uint_as_float(e.x) : -INFINITY;
+            const uint32_t row = have ? e.y : MS_IDX_NONE;
+            const float pv = ms_xor32_f(v, h);
+            const uint32_t prow = ms_xor32_u(row, h);
+            const bool take = row < prow;                 // (the two halves hold distinct rows; both exhausted: nobody)
+            head += take ? 1u : 0u;
+            ms_pair_insert<SAMPLE ? 1 : KL>(st, take ? v : pv, take ? row : prow, h);
+        }
+        ccnt = 0;
+#ifdef MS_STAMP_FLUSH
+        stamp_flush += __builtin_amdgcn_s_memtime() - f0_;
+#endif
+    };
+    auto rare = [&](f32x16 &prev, int tp) __attribute__((always_inline)) {
+        if (AUXM == 2) {            // unit rows: the length mask (dbsearch.py:76,78) is applied here, to the whole tile
+            scale_group(prev, tp, 0); scale_group(prev, tp, 1); scale_group(prev, tp, 2); scale_group(prev, tp, 3);
+        }
+        if constexpr (APPEND) {
+            const uint32_t row0 = (uint32_t)(row_begin + (int64_t)tp * 32) + (uint32_t)(4 * h);
+#define MS_APPEND_GROUP(G)                                                                                              \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                             \
+                const float s_ = prev[4 * (G) + j];                                                                     \
+                const bool pass = s_ > st.tau;                                                                          \
+                if (__ballot(pass) != 0) {                                                                              \
+                    if (pass) {                                                                                         \
+                        float s2_ = s_;                                                                                 \
+                        asm volatile("" : "+v"(s2_));       /* (or hipcc computes all 16 bucket addresses up front: spills) */ \
+                        if (hg.counters != nullptr) ms_hist_count(hg, s2_);                                             \
+                        *cand_slot(ccnt) = ms_u32x2{__float_as_uint(s2_), row0 + (uint32_t)(8 * (G) + j)};              \
+                        ccnt += 1;                                                                                      \
+                    }                                                                                                   \
+                }                                                                                                       \
+            }
+#pragma unroll 1
+            for (int g = 0; g < 4; ++g) {          // (a runtime loop: ONE copy of the flush)
+                int g_ = g;
+                asm volatile("" : "+s"(g_));
+                if (__builtin_expect(__ballot(ccnt > (uint32_t)(LDR_CAND - 4)) != 0, 0)) flush();
+                if (g_ == 0) { MS_APPEND_GROUP(0) } else if (g_ == 1) { MS_APPEND_GROUP(1) } else if (g_ == 2) { MS_APPEND_GROUP(2) } else { MS_APPEND_GROUP(3) }
+            }
+#undef MS_APPEND_GROUP
+        } else {
+            float sc[16];
+            uint64_t m[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
+            ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)tp * 32, r, h, &hg);
+        }
+        if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
+    };
+
 #ifdef MS_STAMP
     unsigned long long stamp_wait = 0, stamp_nwait = 0, stamp_ins = 0, stamp_nins = 0;
 #endif
@@ -1390,15 +1506,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
                              "+v"(areg[6]), "+v"(areg[7]), "+v"(areg[8]), "+v"(areg[9]), "+v"(areg[10]), "+v"(areg[11]), "+v"(areg[12]),
                              "+v"(areg[13]), "+v"(areg[14]), "+v"(areg[15]), "+v"(flag) :: "memory");
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");     // (a counter fetch may be in flight too)
-                float sc[16];
-                uint64_t m[16];
-                if (AUXM == 2) {            // unit rows: the length mask (dbsearch.py:76,78) is applied here, to the whole tile
-                    scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3);
-                }
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
-                ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
-                if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
+                rare(prev, t - 1);
 #ifdef MS_STAMP
                 stamp_ins += __builtin_amdgcn_s_memtime() - i0;
                 stamp_nins += 1;
@@ -1468,13 +1576,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
             // (as in `stage`: the prefetched fragments of the next tile must have landed before compiler-scheduled code runs)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(areg[0]), "+v"(areg[1]), "+v"(areg[2]), "+v"(areg[3]), "+v"(flag) :: "memory");
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(hc0), "+v"(hc1), "+v"(hc2), "+v"(hc3) :: "memory");
-            float sc[16];
-            uint64_t m[16];
-            if (AUXM == 2) { scale_group(prev, t - 1, 0); scale_group(prev, t - 1, 1); scale_group(prev, t - 1, 2); scale_group(prev, t - 1, 3); }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { sc[i] = prev[i]; m[i] = __ballot(sc[i] > st.tau); }
-            ms_tile_insert<SAMPLE ? 1 : KL, true>(st, sc, m, row_begin + (int64_t)(t - 1) * 32, r, h, &hg);
-            if (AUXM == 2) neg_tau = __ballot(st.tau < 0.0f) != 0;
+            rare(prev, t - 1);
 #ifdef MS_STAMP
             stamp_ins += __builtin_amdgcn_s_memtime() - i0;
             stamp_nins += 1;
@@ -1661,6 +1763,7 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
 #pragma unroll
             for (int i = 0; i < 16; ++i) smax = (acc0[i] > smax) ? acc0[i] : smax;       // (NaN scores never enter)
         } else {
+            if constexpr (APPEND) flush();      // (the last tile's rows come after every buffered one)
             float sc[16];
             uint64_t m[16];
 #pragma unroll
@@ -1677,6 +1780,9 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         o[0] = __builtin_amdgcn_s_memtime() - stamp_c0;
         o[1] = __builtin_amdgcn_s_memrealtime() - stamp_r0;
         o[6] = stamp_cm - stamp_c0; o[7] = stamp_rm - stamp_r0;      // first half of the stream (cycles, 100 MHz ticks)
+#ifdef MS_STAMP_FLUSH
+        o[6] = stamp_flush; o[7] = (stamp_nflush << 32) | stamp_rounds;
+#endif
         o[2] = (unsigned long long)ntl;
         o[3] = (stamp_nwait << 40) | stamp_wait;
         o[4] = stamp_ins; o[5] = stamp_nins;
@@ -1758,9 +1864,10 @@ int launch_scan_variant(const ScanPlan &pl, const ScanParams &sp, hipStream_t st
         }
         if (sp.qwb == 4 && loader_wave_setting()) {     // MFMA-bound batches
 #define MS_LAUNCH_LOADER(AUXM)                                                                                           \
+            constexpr int lds_ = KL >= MS_APPEND_MIN_KL ? LDR_LDS_APPEND : LDR_LDS;       /* (the candidate buffers of the append-and-flush rare path) */ \
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_scan_loader_kernel<KL, AUXM, false>),     \
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDR_LDS));                 \
-            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUXM, false>), dim3(pl.grid), dim3(320), LDR_LDS, st, sp);
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds_));                         \
+            hipLaunchKernelGGL((ms_scan_loader_kernel<KL, AUXM, false>), dim3(pl.grid), dim3(320), lds_, st, sp);
             if constexpr (!AUX) { MS_LAUNCH_LOADER(0) }
             else if (sp.unit_rows) { MS_LAUNCH_LOADER(2) }
             else { MS_LAUNCH_LOADER(1) }

@@ -72,7 +72,6 @@ static_assert(PF2_LDS <= 160 * 1024, "LDS of one CU");
 static_assert(MS_HIST_PERIOD >= 16, "eight waves take turns at four staging areas: phases 2 w and 2 w + 2 of a period");
 
 typedef uint32_t ms_u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t ms_u32x2 __attribute__((ext_vector_type(2)));
 
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"

@@ -659,6 +659,12 @@ int hist_setting() {
     return v;
 }
 
+double sample_coef_setting() {      // diagnostics: the constant of the sample-size rule when the shared bound is on
+    static double v = -1.0;
+    if (v < 0.0) { const char *e = getenv("MS_SAMPLE_COEF"); v = e ? atof(e) : 0.05; }
+    return v;
+}
+
 int prepass_tiles_setting() {
     static int v = -2;
     if (v == -2) {
@@ -717,9 +723,14 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
     // tighter than a stream's own list).  Minimum at T0 = sqrt(c * tiles_per_stream * k / streams), c from
     // the measured cost of a tile (2.2 us) and of a candidate (0.27 us): 3 tiles at 31 tiles per stream,
     // 9 at 244, 17 at 977 for k = 10 and 128 streams (sweeps at 125k-16M rows x 256 queries agree).
+    // (... without the shared bound.  With it -- the loader-wave form of the fp32 scan -- the threshold follows the scan and
+    //  the sample only has to start it: the optimum moves to ~0.4 of that, 3-4 tiles at C2 instead of 9 (0.518 against 0.526 ms per
+    //  step) and 9 instead of 22 at k = 64 (0.665 against 0.719); profiles/r04_sample_size_sweep.log)
     pl.prepass_tiles = prepass_tiles_setting();
     if (pl.prepass_tiles < 0) {
-        const double t0 = sqrt(0.3 * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
+        const double c = (qpw == 0 && pl.qwb == 4 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : 0.3;      // (the split-image
+                                     // scan only appends between flushes: its thresholds move with the shared bound alone, and it wants the larger sample)
+        const double t0 = sqrt(c * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
         pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));
     }
     if (tiles_per_stream < 8 * (int64_t)pl.prepass_tiles) pl.prepass_tiles = (int)(tiles_per_stream / 8);

@@ -43,6 +43,11 @@ for n, nq, k in cases:
     st = allw[:, :4, :].reshape(-1, 8); st = st[st[:, 2] > 0]
     ni = st[:, 5].astype(np.float64); ci = st[:, 4].astype(np.float64)
     print(f"   insert path: taken in {100*ni.sum()/st[:,2].astype(np.float64).sum():.1f}% of tiles, {ci.sum()/max(ni.sum(),1):.0f} cycles per visit")
+    if os.environ.get("STAMP_FLUSH") == "1":      # -DMS_STAMP_FLUSH builds: words 6, 7 = cycles in flushes, (flushes << 32) | rounds
+        fl = st[:, 6].astype(np.float64); nf = (st[:, 7] >> np.uint64(32)).astype(np.float64); nr = (st[:, 7] & np.uint64(0xFFFFFFFF)).astype(np.float64)
+        print(f"   flushes per wave median {np.median(nf):.0f} max {nf.max():.0f}; rounds per flush {nr.sum()/max(nf.sum(),1):.1f}; cycles per round {fl.sum()/max(nr.sum(),1):.0f}; "
+              f"flush cycles per wave median {np.median(fl):.0f} of {np.median(ci):.0f} in the rare path")
+        st[:, 6] = 0; st[:, 7] = 0
     cyc, rt, nt = st[:, 0].astype(np.float64), st[:, 1].astype(np.float64), st[:, 2].astype(np.float64)
     ghz = cyc / rt * 0.1
     c1, r1 = st[:, 6].astype(np.float64), st[:, 7].astype(np.float64)

@@ -796,6 +796,46 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
         return;
     }
     __syncthreads();                                   // every wave is done with its tile slot
+    if (MAXONLY) {
+        // Sample pass: a stream's list is two maxima.  The 4/qwb streams of a query tile leave them in LDS, one thread per query
+        // sorts the 2 * spb <= 8 entries (rows are distinct) and writes all p.k ranks (the general merge below took 5.4 us of an
+        // 18.6 us launch: ~20 LDS round trips behind four barriers).
+        uint2 *two = reinterpret_cast<uint2 *>(smem);      // [qw][32 queries][spb][2]
+        if (h == 0) {
+            uint2 *mine = two + (((size_t)qw * 32 + r) * spb + sw) * 2;
+            const bool act = active;
+            mine[0] = act ? make_uint2(__float_as_uint(ls[0]), li[0]) : make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
+            mine[1] = act ? make_uint2(__float_as_uint(ls[1]), li[1]) : make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
+        }
+        __syncthreads();
+        if (tid < p.qwb * 32) {
+            const int pqw = tid >> 5, pq = tid & 31;
+            const int qt = qg * p.qwb + pqw;
+            if (qt < p.n_qtiles) {
+                uint2 e[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) e[u] = (u < 2 * spb) ? two[((size_t)pqw * 32 + pq) * spb * 2 + u] : make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
+                // insertion sort of 8 under the total order (static indices: registers)
+#pragma unroll
+                for (int a = 1; a < 8; ++a) {
+#pragma unroll
+                    for (int b2 = a; b2 >= 1; --b2) {
+                        const bool sw_ = ms_better(__uint_as_float(e[b2].x), e[b2].y, __uint_as_float(e[b2 - 1].x), e[b2 - 1].y);
+                        const uint2 hi_ = sw_ ? e[b2] : e[b2 - 1], lo_ = sw_ ? e[b2 - 1] : e[b2];
+                        e[b2 - 1] = hi_; e[b2] = lo_;
+                    }
+                }
+                const size_t o0 = (size_t)(qt * 32 + pq) * p.k * p.P + sgroup;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (u < p.k) { p.part_s[o0 + (size_t)u * p.P] = __uint_as_float(e[u].x); p.part_i[o0 + (size_t)u * p.P] = e[u].y; }
+                for (int u = 8; u < p.k; ++u) { p.part_s[o0 + (size_t)u * p.P] = -INFINITY; p.part_i[o0 + (size_t)u * p.P] = MS_IDX_NONE; }
+            }
+        }
+        MS_BODY_STAMP(4);
+        MS_BODY_STAMP(5);
+        return;
+    }
     uint2 *lists = reinterpret_cast<uint2 *>(smem);    // [qw][sw][32 queries][K2]
     {
         uint2 *mine = lists + ((size_t)(qw * spb + sw) * 32 + r) * K2 + h * KL;
@@ -803,73 +843,37 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
         for (int j = 0; j < KL; ++j) mine[j] = make_uint2(__float_as_uint(ls[j]), li[j]);
     }
     __syncthreads();
-    // The 4/qwb stream lists of a query (sorted, K2 entries each, empty slots last) -> its best p.k, by rank: every entry is its
-    // own position plus, per other list, a binary search for the entries that beat it (rows are distinct, so are ranks).
-    uint2 *merged = lists + 128 * K2;                  // [qwb * 32 queries][p.k]
-    for (int e = tid; e < p.qwb * 32 * p.k; e += 256) merged[e] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
-    __syncthreads();
-    {
-        // (the searches of a thread's items run in lockstep: C items x spb lists independent LDS reads per step)
-        constexpr int STEP0 = K2 >= 64 ? 64 : (K2 >= 32 ? 32 : (K2 >= 16 ? 16 : (K2 >= 8 ? 8 : (K2 >= 4 ? 4 : 2))));
-        constexpr int PER_THREAD = K2 / 2;             // 128 * K2 items over 256 threads
-        constexpr int C = (PER_THREAD % 5 == 0) ? 5 : ((PER_THREAD % 4 == 0) ? 4 : 1);
-        for (int c0 = 0; c0 < PER_THREAD; c0 += C) {
-            uint2 e[C];
-            const uint2 *grp[C];
-            int mys[C], lo[C][4];
+    // The 4/qwb stream lists of a query (sorted, K2 entries each, empty slots last) -> its best p.k: one thread per query advances the
+    // best of the list heads p.k times and writes as it goes (rows are distinct: a total order).  One barrier; the general
+    // rank-by-binary-search merge that stood here (four barriers, ~80 LDS round trips per thread) took 6 us of every launch.
+    if (tid < p.qwb * 32) {
+        const int pqw = tid >> 5, pq = tid & 31;
+        const int qt = qg * p.qwb + pqw;
+        if (qt < p.n_qtiles) {
+            const uint2 none = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
+            const uint2 *L0 = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;      // list u of the query: + u * 32 * K2
+            uint2 head[4];
+            int pos[4];
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int it = tid + (c0 + c) * 256;
-                const int li_ = it / K2;               // list index: (pqw * spb + s) * 32 + pq
-                e[c] = lists[it];
-                const int pq = li_ & 31, ws_ = li_ >> 5;
-                const int pqw = ws_ / spb;
-                mys[c] = ws_ - pqw * spb;
-                grp[c] = lists + ((size_t)(pqw * spb) * 32 + pq) * K2;      // list s2 of the group: + s2 * 32 * K2
+            for (int u = 0; u < 4; ++u) { pos[u] = 0; head[u] = (u < spb) ? L0[(size_t)u * 32 * K2] : none; }
+            const size_t o0 = (size_t)(qt * 32 + pq) * p.k * p.P + sgroup;
+            for (int rank = 0; rank < p.k; ++rank) {
+                int best = 0;
+                uint2 bh = head[0];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) lo[c][u] = 0;
-            }
+                for (int u = 1; u < 4; ++u)
+                    if (ms_better(__uint_as_float(head[u].x), head[u].y, __uint_as_float(bh.x), bh.y)) { bh = head[u]; best = u; }
+                p.part_s[o0 + (size_t)rank * p.P] = __uint_as_float(bh.x);
+                p.part_i[o0 + (size_t)rank * p.P] = bh.y;
 #pragma unroll
-            for (int step = STEP0; step >= 1; step >>= 1) {
-                uint2 o[C][4];
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int mid = lo[c][u] + step - 1;
-                        o[c][u] = grp[c][(u < spb ? u : mys[c]) * 32 * K2 + (mid < K2 ? mid : K2 - 1)];
+                for (int u = 0; u < 4; ++u) {
+                    if (u == best && bh.y != MS_IDX_NONE) {
+                        pos[u] += 1;
+                        head[u] = pos[u] < K2 ? L0[(size_t)u * 32 * K2 + pos[u]] : none;
                     }
                 }
-#pragma unroll
-                for (int c = 0; c < C; ++c) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int mid = lo[c][u] + step - 1;
-                        if (mid < K2 && ms_better(__uint_as_float(o[c][u].x), o[c][u].y, __uint_as_float(e[c].x), e[c].y)) lo[c][u] = mid + 1;
-                    }
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const int it = tid + (c0 + c) * 256;
-                const int li_ = it / K2;
-                int rank = 0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rank += (u < spb) ? lo[c][u] : 0;
-                if (e[c].y != MS_IDX_NONE && rank < p.k) merged[(li_ / (32 * spb) * 32 + (li_ & 31)) * p.k + rank] = e[c];
             }
         }
-    }
-    __syncthreads();
-    for (int e = tid; e < p.qwb * 32 * p.k; e += 256) {
-        const int lq = e / p.k, rank = e - lq * p.k;   // lq = qw*32 + q
-        const int pqw = lq >> 5, pq = lq & 31;
-        const int qt = qg * p.qwb + pqw;
-        if (qt >= p.n_qtiles) continue;
-        const uint2 v = merged[e];
-        const size_t o = ((size_t)(qt * 32 + pq) * p.k + rank) * p.P + sgroup;
-        p.part_s[o] = __uint_as_float(v.x);
-        p.part_i[o] = v.y;
     }
     MS_BODY_STAMP(4);
     if (!MAXONLY && p.fin_s != nullptr) {

@@ -277,6 +277,39 @@ def test_loader_wave_scan_with_sample_bound(n, nq, k, torch_gpu):
     assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("k", [33, 48, 64])
+def test_long_lists_append_path_with_ties_in_every_tile(k, torch_gpu):
+    """k > 32 (lists of 32 entries per lane): candidates are buffered in LDS and the lists take them at flushes, a query's two
+    buffers merged in row order -- a database of 64 distinct rows repeated all over makes every tile tie with every other one
+    (the lowest rows must win, whatever the buffering did), then every score equal, then the cosine mode on unit rows with a
+    length mask (the mask is applied in the rare path), and a database too short for a sample pass (no threshold: every row
+    is a candidate and the buffers are emptied inside every tile)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    from oracle import oracle as orc
+    rng = np.random.default_rng(k)
+    n, nq = 200_000, 130
+    base = _norm_db(64, seed=7)
+    db = np.ascontiguousarray(base[rng.integers(0, 64, size=n)])
+    q = _norm_db(nq, seed=8)
+    s, i = ops.ip_topk(_dev(torch, db), _dev(torch, q), k, row_offset=11)
+    s_ref, i_ref = orc.ip_topk(db, q, k, row_offset=11, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref)
+    assert np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+    same = np.tile(base[:1], (n, 1))
+    s, i = ops.ip_topk(_dev(torch, same), _dev(torch, q), k)
+    assert (i.cpu().numpy() == np.arange(k)[None, :]).all()
+    for n2 in (150_000, 3_000):
+        raw, lengths = syn.raw_database(n2, seed=92)
+        raw[rng.integers(0, n2, size=n2 // 2)] = raw[rng.integers(0, 50, size=n2 // 2)]       # half the rows repeat 50 of them
+        rq, qlen = syn.raw_queries(nq, seed=93)
+        unit = ops.l2_normalize_rows_(_dev(torch, raw), 1e-8)
+        s, i = ops.ip_topk(unit, _dev(torch, rq), k, mode=ops.MODE_COSINE_UNIT, lengths=_dev(torch, lengths), qlen=_dev(torch, qlen), mincov=0.7)
+        s_ref, i_ref = orc.cosine_topk(raw, rq, k, lengths, qlen, 0.7)
+        assert_topk_equivalent(s.cpu().numpy(), i.cpu().numpy(), s_ref, i_ref, tol=COS_TOL)
+
+
 def test_loader_wave_all_equal_scores_and_cosine_mask(torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops

@@ -56,7 +56,7 @@ constexpr int PF2_W = MS_PF2_W;                // ... then waits for its pieces 
 // issues tile t + D during stage t, every wave has pulled tiles <= t + 1 - W into registers, and the slot of tile t + D - R is free
 // as long as R >= D + W - 1.  A wave may run W - 1 tiles ahead of the slowest one; its pieces have D - W stages to arrive before
 // it waits for them.
-static_assert(PF2_W >= 2 && PF2_D - PF2_W >= 2 && PF2_R >= PF2_D + PF2_W - 1, "ring geometry");
+static_assert(PF2_W >= 2 && PF2_D - PF2_W >= 1 && PF2_R >= PF2_D + PF2_W - 1, "ring geometry");
 constexpr int PF2_AUXR = 16;                   // aux ring: the row lengths of a tile (256 B per slot), cosine mode
 constexpr int PF2_CAND = 4;                    // candidates a lane buffers before the lists take them
 constexpr int PF2_OFF_AUX = PF2_R * 16384;
@@ -167,20 +167,30 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     // publication: this wave's pieces of tile t have landed -> one more arrival at the tile's counter
     const uint32_t arr_lds = ring_lds + PF2_OFF_CNT;
     auto publish = [&](int t) __attribute__((always_inline)) {
+#ifdef MS_PF2_PUBLISH_C
         if (lane == 0) __hip_atomic_fetch_add((__attribute__((address_space(3))) uint32_t *)(arrived + (t & (PF2_ARR - 1))), 1u, __ATOMIC_RELAXED,
                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        // (one lane adds, under an EXEC mask set by scalar moves -- the code is wave-uniform here, EXEC is all ones: five
+        //  instructions; hipcc's `if (lane == 0) atomic add` is fifteen, with two branches, in every stage)
+        const uint32_t a_ = arr_lds + 4u * (uint32_t)(t & (PF2_ARR - 1));
+        uint32_t pub_a, pub_one;
+        asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, 1\n\ts_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1"
+                     : "=&v"(pub_a), "=&v"(pub_one) : "s"(a_) : "memory");
+#endif
     };
     // every wave's pieces of tile t have landed: its counter has been raised NW times per use of it
     uint32_t seen = 0;                                  // the counter of the tile the next stage needs, as last read
     auto read_arrived = [&](int t) __attribute__((always_inline)) { seen = arrived[t & (PF2_ARR - 1)]; };
     auto wait_arrived = [&](int t) __attribute__((always_inline)) {
         const uint32_t need = (uint32_t)NW * (uint32_t)(t / PF2_ARR + 1);
+        uint32_t spins = 0;
 #pragma unroll 1
-        for (uint32_t spins = 0; (uint32_t)__builtin_amdgcn_readfirstlane(seen) < need; ++spins) {
-            if (spins > (1u << 24)) __builtin_trap();             // never a silent hang
+        for (; (uint32_t)__builtin_amdgcn_readfirstlane(seen) < need && spins < (1u << 24); ++spins) {
             __builtin_amdgcn_s_sleep(1);
             read_arrived(t);
         }
+        if (__builtin_expect(spins >= (1u << 24), 0)) __builtin_trap();      // never a silent hang
         asm volatile("" ::: "memory");          // (the tile's fragment reads stay behind the wait)
     };
     (void)arr_lds;
@@ -374,7 +384,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(6)
         // own pieces of tile t + W have landed (issued D - W stages ago; the tail of a stream drains): one more arrival for that tile
+        PF2_ACC(sp_chain)
         if (STEADY || issuing) wait_own(std::integral_constant<int, PF2_D - PF2_W>{}); else ms_pf2_vmcnt<0>();
+        PF2_ACC(sp_flow)         // (diagnostic builds: cycles stalled on this wave's own pieces, inside the chain)
         if (STEADY || t + PF2_W < ntl) publish(t + PF2_W);
         read_arrived(t + 2);                                    // for the next stage (the other waves publish during their chains)
         __builtin_amdgcn_sched_barrier(0);
@@ -390,9 +402,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
 #pragma unroll
             for (int i = 0; i < 16; ++i) smax = (pv[i] > smax) ? pv[i] : smax;       // (NaN scores never enter)
         } else {
-            float mx = pv[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) mx = fmaxf(mx, pv[i]);
+            // (eight instructions; `fmaxf` compiles to ten: hipcc canonicalises the first two operands.  v_max3 ignores NaNs as fmaxf does)
+            // (ONE statement: hipcc pads every asm statement with an s_nop)
+            float mx;
+            asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max3_f32 %0, %0, %8, %9\n\t"
+                "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"
+                : "=&v"(mx) : "v"(pv[0]), "v"(pv[1]), "v"(pv[2]), "v"(pv[3]), "v"(pv[4]), "v"(pv[5]), "v"(pv[6]), "v"(pv[7]), "v"(pv[8]), "v"(pv[9]),
+                  "v"(pv[10]), "v"(pv[11]), "v"(pv[12]), "v"(pv[13]), "v"(pv[14]), "v"(pv[15]));
 #ifdef MS_PF2_NOVISIT
             asm volatile("" ::"v"(mx));
             if (false) {

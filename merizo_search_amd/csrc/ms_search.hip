@@ -725,10 +725,11 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
     // 9 at 244, 17 at 977 for k = 10 and 128 streams (sweeps at 125k-16M rows x 256 queries agree).
     // (... without the shared bound.  With it -- the loader-wave form of the fp32 scan -- the threshold follows the scan and
     //  the sample only has to start it: the optimum moves to ~0.4 of that, 3-4 tiles at C2 instead of 9 (0.518 against 0.526 ms per
-    //  step) and 9 instead of 22 at k = 64 (0.665 against 0.719); profiles/r04_sample_size_sweep.log)
+    //  step) and 9 instead of 22 at k = 64 (0.665 against 0.719); profiles/r04_sample_size_sweep.log.  Below k = 5 the sample's best and
+    //  k-th best scores are too close for the histogram to have buckets: the old rule)
     pl.prepass_tiles = prepass_tiles_setting();
     if (pl.prepass_tiles < 0) {
-        const double c = (qpw == 0 && pl.qwb == 4 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : 0.3;      // (the split-image
+        const double c = (qpw == 0 && pl.qwb == 4 && pl.k_pass >= 5 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : 0.3;      // (the split-image
                                      // scan only appends between flushes: its thresholds move with the shared bound alone, and it wants the larger sample)
         const double t0 = sqrt(c * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
         pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));

@@ -35,6 +35,15 @@ for n, nq, k in cases:
     hist, sync = f(st[:, 7] >> np.uint64(32)), f(st[:, 7] & np.uint64(0xFFFFFFFF))
     print(f"n={n} nq={nq} k={k}: scan {e0.elapsed_time(e1)*1e3:.1f} us | waves {len(st)} tiles/wave {nt.mean():.0f} | cycles/tile median {np.median(cyc/nt):.0f} "
           f"max {np.max(cyc/nt):.0f} | clock {np.median(cyc/rt)*0.1:.3f} GHz | wave time max {rt.max()/100:.1f} us median {np.median(rt)/100:.1f} us")
-    print(f"   per tile (median over waves): lgkm wait {np.median(lg/nt):.0f}, flow-control {np.median(flow/nt):.0f}, issue+vmcnt+landed {np.median(sync/nt):.0f}, "
+    print(f"   per tile (median over waves): lgkm wait {np.median(lg/nt):.0f}, own pieces (in-chain vmcnt) {np.median(flow/nt):.0f}, issue+vmcnt+landed {np.median(sync/nt):.0f}, "
           f"chain(+frag reads) {np.median(chain/nt):.0f}, visits {np.median(vis/nt):.0f} ({100*nvis.sum()/nt.sum():.1f} % of tiles x qtiles... {vis.sum()/max(nvis.sum(),1):.0f} cycles each), hist {np.median(hist/nt):.0f}")
+    allw = buf.reshape(-1, 8, 8)
+    act = allw[:, 0, 2] > 0
+    for w in range(8):
+        ww = allw[act, w, :]
+        ww = ww[ww[:, 2] > 0]
+        if not len(ww): continue
+        ntw = f(ww[:, 2])
+        print(f"   wave {w}: arrival wait/tile {np.median(f(ww[:, 7] & np.uint64(0xFFFFFFFF)) / ntw):.0f}  chain/tile {np.median(f(ww[:, 6]) / ntw):.0f}  "
+              f"visits/tile {np.median(f(ww[:, 4]) / ntw):.0f}  cycles/tile {np.median(f(ww[:, 0]) / ntw):.0f}")
     del d, img

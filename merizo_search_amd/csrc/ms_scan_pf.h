@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     auto read_arrived = [&](int t) __attribute__((always_inline)) { seen = arrived[t & (PF2_ARR - 1)]; };
     auto wait_arrived = [&](int t) __attribute__((always_inline)) {
         const uint32_t need = (uint32_t)NW * (uint32_t)(t / PF2_ARR + 1);
+#ifdef MS_PF2_WAIT_C
         uint32_t spins = 0;
 #pragma unroll 1
         for (; (uint32_t)__builtin_amdgcn_readfirstlane(seen) < need && spins < (1u << 24); ++spins) {
@@ -191,6 +192,34 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
             read_arrived(t);
         }
         if (__builtin_expect(spins >= (1u << 24), 0)) __builtin_trap();      // never a silent hang
+#else
+        // ONE asm statement: the snapshot is good -> four instructions and a short forward branch (hipcc's loop around the same
+        // test is nineteen instructions with a taken branch even when there is nothing to wait for).  Bounded: never a silent hang.
+        uint32_t sv_, spins_, av_;
+        static_assert(PF2_ARR == 16, "the mask below");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %0, %2\n\t"
+                     "s_cmp_ge_u32 %0, %5\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_and_b32 %0, %4, 15\n\t"           // (the counter's address: only needed on this path)
+                     "s_lshl_b32 %0, %0, 2\n\t"
+                     "s_add_u32 %0, %0, %6\n\t"
+                     "v_mov_b32 %3, %0\n\t"
+                     "s_mov_b32 %1, 0\n\t"
+                     "1:\n\t"
+                     "s_sleep 1\n\t"
+                     "ds_read_b32 %2, %3\n\t"
+                     "s_add_u32 %1, %1, 1\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "v_readfirstlane_b32 %0, %2\n\t"
+                     "s_cmp_ge_u32 %0, %5\n\t"
+                     "s_cbranch_scc1 2f\n\t"
+                     "s_cmp_lt_u32 %1, 0x1000000\n\t"
+                     "s_cbranch_scc1 1b\n\t"
+                     "s_trap 2\n\t"                        // never a silent hang
+                     "2:"
+                     : "=&s"(sv_), "=&s"(spins_), "+v"(seen), "=&v"(av_) : "s"(t), "s"(need), "s"(arr_lds) : "memory", "scc");
+#endif
         asm volatile("" ::: "memory");          // (the tile's fragment reads stay behind the wait)
     };
     (void)arr_lds;

@@ -262,6 +262,7 @@ __global__ __launch_bounds__(256) void ms_egnn_proj_kernel(const float *__restri
         f32x4 qa[PF], qb[PF];
 #pragma unroll
         for (int u = 0; u < PF; ++u) { qa[u] = w1a[u * KQ + cq]; qb[u] = w1b[u * KQ + cq]; }
+#pragma unroll 1      // (left to itself hipcc unrolls all 16 rounds and hoists their 256 weight loads: the NJ = 1 instantiation took 512 registers and 548 bytes of scratch)
         for (int k0 = 0; k0 < DIM; k0 += PF) {
             f32x4 ca[PF], cb[PF];
 #pragma unroll

@@ -194,6 +194,11 @@ __device__ __forceinline__ float ms_wave_sum_xor(float v) {       // the butterf
     return v;
 }
 
+// (MS_BODY_DMA_AUX: the rows of a few-query search are read ONCE, by one workgroup -- the non-temporal policy, `nt`, of the guide's
+//  weight streams: 6.4 -> 6.5-6.8 TB/s there)
+#ifndef MS_BODY_DMA_AUX
+#define MS_BODY_DMA_AUX 2
+#endif
 // One wave = one (query tile, row stream) pair, one wave per SIMD; waves never synchronise
 // with each other inside the scan.  The loop over 32-row tiles is software-pipelined around
 // the dependent chain of 64 v_mfma_f32_32x32x2_f32 of tile t (4096 cycles of matrix pipe):
@@ -492,7 +497,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
                 for (int it = 0; it < 16; ++it) {
                     const char *src = tile_src + it * 1024 + off8[it & 7];
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, MS_BODY_DMA_AUX);
                 }
             } else {   // last tile of the database: clamp rows past the end (their scores are discarded)
 #pragma unroll
@@ -501,7 +506,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
                     if (row >= p.n) row = p.n - 1;
                     const char *src = reinterpret_cast<const char *>(p.db) + row * 512 + 16 * ((r ^ h) ^ ((2 * it) & 15));
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(dst + it * 64), 16, 0, MS_BODY_DMA_AUX);
                 }
             }
         };
@@ -667,7 +672,7 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
                 // of this one.  vmcnt(8): everything but the 8 pieces of tile t+2 issued so far.
                 if (tt == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(dma_src + tt * 1024 + off8[tt & 7]),
-                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, 0);
+                                                 (__attribute__((address_space(3))) void *)(dma_dst + tt * 64), 16, 0, MS_BODY_DMA_AUX);
                 if (tt == 15) issue_aux_dma(tnext);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, qreg[4 * tt + 2], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, qreg[4 * tt + 3], acc, 0, 0, 0);

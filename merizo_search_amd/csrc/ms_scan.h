@@ -1006,6 +1006,10 @@ template <int IMM>
 __device__ __forceinline__ void ms_glds_s16(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
 }
+template <int IMM>      // the same with the non-temporal policy (rows that ONE workgroup reads once)
+__device__ __forceinline__ void ms_glds_s16_nt(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");
+}
 template <int IMM>      // the same with sc1: past this CU's L1 (counters other workgroups are adding to)
 __device__ __forceinline__ void ms_glds_s16_sc1(uint32_t lds_addr, uint32_t lane_off, uint64_t sbase) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 sc1" ::"s"(lds_addr - (uint32_t)IMM), "v"(lane_off), "s"(sbase), "i"(IMM) : "memory", "m0");

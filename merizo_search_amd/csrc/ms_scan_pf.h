@@ -141,7 +141,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
             // (uniform values that live across branches: say so again, or the "s" operands of the asm may be handed vector registers)
             const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(it_dst);
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)it_sb), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(it_sb >> 32));
+#ifdef MS_PF2_NT
+            ms_glds_s16_nt<1024 * I>(d + 1024 * I, voff, ((uint64_t)hi << 32) | (uint64_t)lo);
+#else
             ms_glds_s16<1024 * I>(d + 1024 * I, voff, ((uint64_t)hi << 32) | (uint64_t)lo);
+#endif
         }
     };
     auto issue_aux = [&](int t) __attribute__((always_inline)) {

@@ -85,7 +85,8 @@ def small_batch_note(nq, ops=None):
         what = "%s%s scan + merge launches (no sample pass below 8 queries)" % (norm, "," if nq <= inkernel else " +")
     else:
         what = "%s%s sample pass + bound + scan + merge launches" % (norm, "," if nq <= inkernel else " +")
-    return "one ms_ip_topk call per step (MS_MODE_IP_NORMQ): scan_ms = HIP events around that call = " + what
+    return ("one ms_ip_topk call per step (MS_MODE_IP_NORMQ); ms_per_step = wall time over back-to-back calls without event markers; "
+            "scan_ms = HIP events around that call (a separate loop) = " + what)
 
 
 def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
@@ -315,8 +316,15 @@ def hbm_regime(make, rows_list, log):
         for nq in (1, 4, 8, 32):
             b = make(rows, nq)
             steps = 40 if rows <= 4_000_000 else 6
-            elapsed, scan_ms, _ = b.run(steps, 3, prep_budget_s=0.05)
-            ms = elapsed / steps * 1e3
+            _, scan_ms, _ = b.run(steps, 3, prep_budget_s=0.05)
+            # the step time is taken over back-to-back calls WITHOUT event markers between them (two markers per call cost ~10 us of a
+            # 120 us search: the run above, which has them, gives the launch duration only)
+            reps = 100 if rows <= 4_000_000 else 10
+            b.fence(); t0 = time.perf_counter()
+            for _ in range(reps):
+                b.step()
+            b.fence()
+            ms = (time.perf_counter() - t0) / reps * 1e3
             out.append({"rows": rows, "nq": nq, "k": b.k, "ms_per_step": ms, "scan_ms": scan_ms, "queries_per_s": nq / ms * 1e3,
                         "scan_GBps": 512.0 * rows / scan_ms / 1e6, "scan_frac_of_hbm_peak": 512.0 * rows / (scan_ms * 1e-3) / HBM_PEAK,
                         "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k),

@@ -122,7 +122,9 @@ def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
     else:
         roof = {"bound": "hbm", "achieved": bytes_ / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac,
                 "step_frac": bytes_ / (step_ms * 1e-3) / HBM_PEAK}
-    roof.update({"traffic": None, "kernel": scan_kernel_name(nq, k), "kernel_ms": scan_ms, "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
+    roof.update({"traffic": None, "kernel": scan_kernel_name(nq, k), "kernel_ms": scan_ms,
+                 "kernel_ms_from": "HIP events around the scan launch of every %d-th step of the timed region (every step when there are fewer than %d)" % (EVENT_STRIDE, 4 * EVENT_STRIDE),
+                 "mfma_frac": mfma_frac, "hbm_frac": hbm_frac,
                  "rows_per_launch": rows, "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": bytes_})
     return roof
 
@@ -259,10 +261,13 @@ class SearchBench:
         for _ in range(warmup):
             res = self.step()
         self.fence()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        # HIP events around the scan launch of every EVENT_STRIDE-th step of the timed region (a pair of markers costs the stream
+        # ~3 us; around every launch they were 1 % of a C2 step): the launch duration is their mean
+        stride = EVENT_STRIDE if steps >= 4 * EVENT_STRIDE else 1
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(0, steps, stride)]
         t0 = time.perf_counter()
         for s in range(steps):
-            res = self.step(evs[s])
+            res = self.step(evs[s // stride] if s % stride == 0 else None)
         self.fence()
         elapsed = time.perf_counter() - t0
         scan_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
@@ -306,6 +311,9 @@ class SearchBench:
             identical += int(np.array_equal(got[j], bi[j, :k]))
         return {"recall_at_k": float(np.mean(recall)), "recall_queries_checked": nb,
                 "topk_identical_to_torch_bruteforce": "%d of %d queries" % (identical, nb), "planted_recall": planted}
+
+
+EVENT_STRIDE = 4       # SearchBench.run: HIP events around every 4th scan launch of the timed region
 
 
 def hbm_regime(make, rows_list, log):

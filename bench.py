@@ -578,6 +578,10 @@ def main():
         print("[bench] launching %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
         raise SystemExit(subprocess.call(cmd))
 
+    if os.environ.get("MS_BENCH_FAULT_DUMP"):           # diagnostics: every rank dumps its Python stacks to stderr after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["MS_BENCH_FAULT_DUMP"]), repeat=False, exit=False)
+
     import torch
     import torch.distributed as dist
 

@@ -70,3 +70,27 @@ def assert_topk_equivalent(s, i, s_ref, i_ref, tol=2e-6, exact_scores=False):
             else:
                 assert seg_a == seg_b, f"row {row} ranks {j}..{e}: {sorted(seg_a)} vs {sorted(seg_b)}"
             j = e + 1
+
+
+def free_port(count: int = 1) -> int:
+    """A TCP port (the first of `count` consecutive ones) that is free on 127.0.0.1 right now, for the rendezvous of a multi-process
+    test.  (Ports derived from the pytest pid collided now and then with a socket a previous test had left in TIME_WAIT: one GPU suite
+    run in twenty then sat in a rendezvous until its subprocess timeout.)"""
+    import socket
+    for _ in range(200):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        if port + count >= 65535:
+            continue
+        ok = True
+        for extra in range(1, count):
+            with socket.socket() as sk2:
+                try:
+                    sk2.bind(("127.0.0.1", port + extra))
+                except OSError:
+                    ok = False
+                    break
+        if ok:
+            return port
+    raise RuntimeError("no free port found")

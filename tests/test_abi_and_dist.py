@@ -113,7 +113,8 @@ def test_sharded_search_two_ranks_gloo(tmp_path):
     the oracle engine standing in for the GPU kernels: sharded == unsharded, bit for bit."""
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
-    port = str(29500 + os.getpid() % 2000)
+    from conftest import free_port
+    port = str(free_port())
     env = dict(os.environ, OMP_NUM_THREADS="2")
     procs = [subprocess.Popen([sys.executable, str(script), REPO, port, str(r), "2"], stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT, text=True, env=env) for r in range(2)]

@@ -412,9 +412,15 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     if (row >= 0) {
         const float4 *x = reinterpret_cast<const float4 *>(db + (size_t)row * MS_DIM);
         float acc = 0.0f;
-#pragma unroll 4
+        // (the whole row requested before the chain starts: four batches of eight loads, each a round trip to a row nobody has
+        //  touched, were most of this kernel's 14 us)
+        float4 xl[16], xh[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) { xl[t] = x[t]; xh[t] = x[16 + t]; }
+        __builtin_amdgcn_sched_barrier(0);          // (or hipcc pulls the loads back next to their uses, eight at a time)
+#pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float4 lo = x[t], hi = x[16 + t];
+            const float4 lo = xl[t], hi = xh[t];
             acc = fmaf(lo.x, qs[4 * t + 0], acc); acc = fmaf(hi.x, qs[64 + 4 * t + 0], acc);
             acc = fmaf(lo.y, qs[4 * t + 1], acc); acc = fmaf(hi.y, qs[64 + 4 * t + 1], acc);
             acc = fmaf(lo.z, qs[4 * t + 2], acc); acc = fmaf(hi.z, qs[64 + 4 * t + 2], acc);

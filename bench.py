@@ -112,9 +112,7 @@ def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
                      "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "split_bf16_mfma_frac": bf16_frac,
                      "algorithmic_tflops": flops / t / 1e12, "rows_per_launch": rows, "algorithmic_bytes_per_launch": bytes_,
                      "algorithmic_flops_per_launch": flops, "executed_bf16_flops_per_launch": executed,
-                     "note": "achieved / frac (matrix-bound shapes) count the flops the launch EXECUTES: 3 bf16 matrix instructions per 16 "
-                             "dimensions = 3 x the algorithmic flops, against the dense bf16 matrix peak -- the roof of this arithmetic; "
-                             "algorithmic_tflops is the un-tripled figure (it may exceed the fp32 matrix peak: this is not fp32 matrix work)"})
+                     "note": "see notes.prefiltered_roofline"})
         return roof
     if nq >= 39:
         roof = {"bound": "mfma", "achieved": flops / t / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s", "frac": mfma_frac,
@@ -140,7 +138,8 @@ def attach_committed_traffic(roof, pmc_name):
         pmc = json.load(fh)
     roof["traffic"] = pmc.get("traffic_bytes_per_launch")
     roof["traffic_from_committed_profile"] = True
-    roof["traffic_source"] = "profiles/%s: %s (committed rocprofv3 --pmc passes, not measured in this run)" % (pmc_name, pmc.get("workload", ""))
+    roof["traffic_source"] = "profiles/%s" % pmc_name
+    roof["traffic_from"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload)" % pmc_name
     if pmc.get("matrix_pipe_busy_fraction") is not None:
         roof["matrix_pipe_busy_fraction_from_committed_profile"] = pmc["matrix_pipe_busy_fraction"]
 
@@ -277,6 +276,25 @@ class SearchBench:
             elapsed, scan_ms = float(t[0]), float(t[1])
         return elapsed, scan_ms, res
 
+    def local_rate(self, steps):
+        """queries/s of the ranks' own shard scans WITHOUT the exchange and the shard merge (slowest rank): what one GPU does on
+        its share of the database -- the one-rank reference point of the weak-scaling curve, measured by the same processes."""
+        keep, self.exchange = self.exchange, False
+        try:
+            self.step(); self.fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step()
+            self.fence()
+            el = time.perf_counter() - t0
+        finally:
+            self.exchange = keep
+        if self.world > 1:
+            t = self.torch.tensor([el], dtype=self.torch.float64, device=self.db.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            el = float(t[0])
+        return self.nq * steps / el
+
     def check(self, res, sharded):
         """Correctness of what was timed, after the timed region: recall@k against an exact brute force
         (torch matmul + topk over every shard, merged over the ranks) -- for every query when the score
@@ -336,7 +354,7 @@ def hbm_regime(make, rows_list, log):
             out.append({"rows": rows, "nq": nq, "k": b.k, "ms_per_step": ms, "scan_ms": scan_ms, "queries_per_s": nq / ms * 1e3,
                         "scan_GBps": 512.0 * rows / scan_ms / 1e6, "scan_frac_of_hbm_peak": 512.0 * rows / (scan_ms * 1e-3) / HBM_PEAK,
                         "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k),
-                        "note": small_batch_note(nq, b.ops)})
+                        "note": "see notes.small_batch.nq%d" % nq})
             log("hbm_regime rows=%d nq=%d: call %.3f ms (%.1f%% of 8 TB/s), step %.3f ms (%.1f%%)" % (rows, nq, scan_ms, out[-1]["scan_frac_of_hbm_peak"] * 100, ms, out[-1]["step_frac_of_hbm_peak"] * 100))
             del b
     return out
@@ -549,6 +567,121 @@ def cpu_baseline(db, q_unit, k, n_total, sd, embed_coords):
     return out
 
 
+LINE_LIMIT = 4096          # bytes: the driver keeps a ~10 KB tail of the output; round 4's 22 KB line did not parse
+
+
+def _r(x, nd=4):
+    """Numbers of the compact line: 6 significant digits are more than any of them carries."""
+    if isinstance(x, str):
+        return x[:120]
+    if isinstance(x, bool) or x is None or isinstance(x, int):
+        return x
+    return float("%.6g" % x)
+
+
+def _roof_short(roof):
+    """The contract's roofline object: bound / achieved / peak / unit / frac / traffic, plus the kernel it is about, its launch
+    duration (HIP events, this run), the same work over the whole step, and where `traffic` came from."""
+    if roof is None:
+        return None
+    out = {key: _r(roof.get(key)) for key in ("bound", "achieved", "peak", "unit", "frac", "step_frac", "traffic")}
+    out["kernel"] = str(roof.get("kernel", ""))[:64]
+    out["kernel_ms"] = _r(roof.get("kernel_ms"))
+    for key in ("mfma_frac", "hbm_frac"):
+        if roof.get(key) is not None:
+            out[key] = _r(roof[key])
+    if roof.get("traffic") is not None:
+        out["traffic_from"] = str(roof.get("traffic_from", "profiles/ (committed rocprofv3 --pmc passes)"))[:96]
+    return out
+
+
+def compact_line(doc, full_path=None):
+    """The ONE line the driver parses: the contract's keys, the top-level roofline, a short `prefiltered` summary, `cpu_baseline`
+    and a handful of headline numbers of the other entries -- always under LINE_LIMIT bytes (tests/test_bench_line.py).  The full
+    document (every block, every note) goes to `bench_full.json` beside this file."""
+    cfg = doc.get("config", {})
+    line = {key: _r(doc.get(key)) for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                              "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = str(line["metric"])[:120]
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:200]}
+    for key in ("db_rows", "rows_per_gpu", "dim", "queries_per_step", "k"):
+        if key in cfg:
+            line["config"][key] = cfg[key]
+    line["config"]["path"] = "fp32 scan (ms_ip_topk), v_mfma_f32_32x32x2_f32"
+    line["config"]["parallelism"] = str(cfg.get("sharding", ""))[:90]
+    for key in ("recall_at_k", "planted_recall", "topk_identical_to_torch_bruteforce", "weak_scaling_ref_q_per_s", "vs_ref"):
+        if doc.get(key) is not None:
+            line[key] = _r(doc[key])
+    line["roofline"] = _roof_short(doc.get("roofline"))
+    pf = doc.get("prefiltered")
+    if pf:
+        line["prefiltered"] = {"ms_per_step": _r(pf["ms_per_step"]), "queries_per_s": _r(pf["queries_per_s"]), "dtype": str(pf.get("dtype", ""))[:48],
+                               "identical_to_fp32": pf.get("identical_to_fp32"), "exact_pass_queries": pf.get("exact_pass_queries"),
+                               "roofline": _roof_short(pf.get("roofline"))}
+    cb = doc.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": _r(cb["unit"]), "cores": cb["cores"], "kind": _r(cb["kind"]),
+                                "sample": str(cb.get("sample", ""))[:140], "host": str((cb.get("host") or {}).get("cpu_model", ""))[:48]}
+    # headline numbers of the other entries (everything else about them: the full document)
+    more = {}
+    c4 = doc.get("c4_shard")
+    if c4:
+        more["c4_shard"] = {"queries_per_s": _r(c4["queries_per_s"]), "ms_per_step": _r(c4["ms_per_step"]), "frac": _r(c4["roofline"]["frac"])}
+        if c4.get("prefiltered"):
+            more["c4_shard"]["prefiltered_queries_per_s"] = _r(c4["prefiltered"]["queries_per_s"])
+            more["c4_shard"]["prefiltered_frac"] = _r(c4["prefiltered"]["roofline"]["frac"])
+            more["c4_shard"]["prefiltered_identical"] = c4["prefiltered"].get("identical_to_fp32")
+    if doc.get("c4_full"):
+        more["c4_full"] = {key: _r(v) for key, v in doc["c4_full"].items() if key in ("rows", "queries_per_s", "ms_per_step", "frac", "identical_to_8_shards")}
+    hb = doc.get("hbm_regime")
+    if hb:
+        more["hbm_regime_step_frac"] = {"%dM_nq%d" % (round(e["rows"] / 1e6), e["nq"]): _r(float("%.3g" % e["step_frac_of_hbm_peak"])) for e in hb}
+    em = doc.get("embed")
+    if em:
+        more["embed"] = {"embeds_per_s": _r(em["embeds_per_s"]), "frac": _r(em["roofline"]["frac"])}
+        if em.get("c5_query"):
+            more["embed"]["c5_query_ms"] = _r(em["c5_query"].get("embed_ms_three_domains"))
+    c3 = doc.get("c3_search")
+    if c3:
+        more["c3_search"] = {"ms_per_step": _r(c3["ms_per_step"]), "frac": _r(c3["roofline"]["frac"])}
+        if c3.get("prefiltered"):
+            more["c3_search"]["prefiltered_ms_per_step"] = _r(c3["prefiltered"]["ms_per_step"])
+    if doc.get("c3_end_to_end"):
+        more["c3_end_to_end_domains_per_s"] = _r(doc["c3_end_to_end"]["domains_per_s"])
+    cl = doc.get("clustered")
+    if cl and cl.get("prefiltered"):
+        more["clustered_prefiltered"] = {"queries_per_s": _r(cl["prefiltered"]["queries_per_s"]), "exact_pass_queries": cl["prefiltered"].get("exact_pass_queries"),
+                                         "identical_to_fp32": cl["prefiltered"].get("identical_to_fp32")}
+    if more:
+        line["more"] = more
+    if full_path:
+        line["full"] = os.path.basename(full_path)
+    text = json.dumps(line, separators=(",", ":"))
+    # belt and braces: never over the limit, whatever the blocks above grew into
+    for key in ("more", "prefiltered"):
+        if len(text) < LINE_LIMIT:
+            break
+        line.pop(key, None)
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:
+        raise RuntimeError("bench line is %d bytes (limit %d)" % (len(text), LINE_LIMIT))
+    return text
+
+
+def write_full(doc):
+    """The full document -> bench_full.json beside bench.py (the temp dir when that is read-only); -> path or None."""
+    import tempfile
+    for d in (REPO, tempfile.gettempdir()):
+        try:
+            path = os.path.join(d, "bench_full.json")
+            with open(path, "w") as fh:
+                json.dump(doc, fh, indent=1)
+            return path
+        except OSError:
+            continue
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -557,6 +690,9 @@ def main():
     ap.add_argument("--rows", type=int, default=None, help="TOTAL database rows, sharded over the ranks (default: 1M at N=1; 45,625,000 PER GPU at N>1)")
     ap.add_argument("--nq", type=int, default=None, help="queries per step (default 256 at N=1, 4096 at N>1)")
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--shape", choices=("c2", "c4"), default=None,
+                    help="N=1 only: c2 (default) = 1M rows x 256 queries; c4 = ONE rank's share of C4 (45,625,000 rows x 4096 queries) as the top-level "
+                         "step -- the like-for-like first point of the weak-scaling curve that --gpus N>1 measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip hbm_regime / c4_shard / embed")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the `prefiltered` blocks (the top-level line is the fp32 scan either way)")
@@ -613,7 +749,13 @@ def main():
 
     k = args.k
     weak = world > 1 and args.rows is None
-    if world == 1:
+    if world > 1 and args.shape == "c2":
+        raise SystemExit("--shape c2 is the one-GPU workload; --gpus N > 1 always runs the C4 shape (weak scaling)")
+    if world == 1 and args.shape == "c4":
+        n_total, nq = args.rows or int(os.environ.get("MS_BENCH_ROWS_PER_GPU", C4_ROWS_PER_GPU)), args.nq or C4_NQ
+        if args.steps == ap.get_default("steps"):
+            args.steps, args.warmup = 10, 2                               # 0.34 s per step
+    elif world == 1:
         n_total, nq = args.rows or 1_000_000, args.nq or 256
     else:
         rows_per_gpu = int(os.environ.get("MS_BENCH_ROWS_PER_GPU", C4_ROWS_PER_GPU))
@@ -626,6 +768,8 @@ def main():
     steps = args.steps
     elapsed, scan_ms, res = bench.run(steps, args.warmup)        # the fp32 scan: the reference's arithmetic, data-independent
     checks = bench.check(res, sharded)
+    # N > 1 (weak scaling): the same ranks' shard scans without the exchange -- the curve's one-rank reference from the same build
+    local_ref = bench.local_rate(max(2, min(steps, 10))) if world > 1 else None
 
     def pf_block(b_fp32, res_fp32, steps_, warm_, prep_s=0.3, pmc=None):
         """The same step through the prefiltered search (the path the driver takes for this shape)."""
@@ -640,10 +784,7 @@ def main():
                "exact_pass_queries": ops.prefilter_flagged(bp.ws) if world == 1 else None,
                "split_image_bytes": int(bp.image.numel()),
                "roofline": roofline(bp.nq, bp.n_local, bp.k, sc, ms, prefiltered=True),
-               "note": "ms_ip_topk_prefiltered over the split-bf16 image built when the database became resident (512 B per row next to the "
-                       "fp32 rows); the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, an exact "
-                       "fp32 pass for the queries whose proof failed (exact_pass_queries of them); results bit-identical to the fp32 scan "
-                       "(tests/test_prefilter_gpu.py)"}
+               "note": "see notes.prefiltered"}
         if pmc is not None:
             attach_committed_traffic(blk["roofline"], pmc)
         del bp
@@ -659,6 +800,8 @@ def main():
             attach_committed_traffic(roof, "r04_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
+        elif world == 1 and args.shape == "c4":
+            workload = "C4 shape, ONE rank's share: %d x 128 fp32 synthetic DB rows, batch=%d queries, top-%d, 1 MI355X (the N=1 point of the weak-scaling curve)" % (n_total, nq, k)
         elif weak:
             workload = "C4 shape: TED-scale %d x 128 fp32 synthetic DB row-sharded over %d GPUs (%d rows each), batch=%d queries, top-%d, RCCL all-gather of per-shard top-k" % (
                 n_total, world, bench.n_local, nq, k)
@@ -677,6 +820,11 @@ def main():
                        "scaling_note": "weak: rows per GPU fixed, the database grows with N, so ideal queries/s is CONSTANT in N (row x query "
                                        "rate grows N-fold); compare with c4_shard of the N=1 run" if weak else None},
             "row_queries_per_s": float(n_total) * nq * steps / elapsed,
+            "weak_scaling_ref_q_per_s": local_ref,
+            "vs_ref": (nq * steps / elapsed) / local_ref if local_ref else None,
+            "weak_scaling_ref_note": ("the same ranks' shard scans timed WITHOUT the all-gather and the shard merge (slowest rank): the one-GPU rate on one "
+                                      "45.6M-row share; weak scaling holds queries/s constant while the database grows N-fold, so vs_ref is the scaling "
+                                      "efficiency against this build's own one-rank point (`python bench.py --gpus 1 --shape c4` measures it alone)") if local_ref else None,
             "roofline": roof,
             "prefiltered": pf_main,
         }
@@ -688,7 +836,7 @@ def main():
         line = None
 
     extras_sd, extras_coords = None, None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and args.shape != "c4":
         db_keep, q_keep = bench.db, bench.q_raw
         del bench.ws
         mk = lambda rows, nq_, **kw_: SearchBench(torch, dist, ops, syn, sharded, dev, 0, 1, rows, 0, rows, nq_, k, **kw_)
@@ -740,7 +888,7 @@ def main():
                 small.append({"rows": C4_ROWS_PER_GPU, "nq": nq_, "k": k, "ms_per_step": ms, "scan_ms": sc, "queries_per_s": nq_ / ms * 1e3,
                               "scan_GBps": 512.0 * C4_ROWS_PER_GPU / sc / 1e6, "scan_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (sc * 1e-3) / HBM_PEAK,
                               "step_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq_, k),
-                              "note": small_batch_note(nq_, ops)})
+                              "note": "see notes.small_batch.nq%d" % nq_})
                 log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s)" % (C4_ROWS_PER_GPU, nq_, sc, small[-1]["scan_frac_of_hbm_peak"] * 100))
                 del b
             line["hbm_regime"] += small
@@ -772,7 +920,23 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             q_unit = bench.q_raw / bench.q_raw.norm(dim=1, keepdim=True)
             line["cpu_baseline"] = cpu_baseline(bench.db, q_unit, k, n_total, extras_sd, extras_coords)
-        print(json.dumps(line), flush=True)
+        line["notes"] = {
+            "prefiltered": "ms_ip_topk_prefiltered over the split-bf16 image built when the database became resident (512 B per row next to the "
+                           "fp32 rows); the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, an exact "
+                           "fp32 pass for the queries whose proof failed (exact_pass_queries of them); results bit-identical to the fp32 scan "
+                           "(tests/test_prefilter_gpu.py)",
+            "prefiltered_roofline": "achieved / frac (matrix-bound shapes) count the flops the launch EXECUTES: 3 bf16 matrix instructions per 16 "
+                                    "dimensions = 3 x the algorithmic flops, against the dense bf16 matrix peak -- the roof of this arithmetic; "
+                                    "algorithmic_tflops is the un-tripled figure (it may exceed the fp32 matrix peak: this is not fp32 matrix work)",
+            "traffic": "roofline.traffic = HBM bytes per launch from the rocprofv3 --pmc passes named in traffic_source (gfx950 corrections: "
+                       "tools/pmc_to_json.py); counters need the profiler, so they are not collected inside this run",
+            "small_batch": {"nq%d" % q_: small_batch_note(q_, ops) for q_ in (1, 4, 8, 32)},
+        }
+        full_path = write_full(line)
+        print(json.dumps(line), file=sys.stderr, flush=True)                 # the full document: stderr and bench_full.json
+        log("full document: %s" % full_path)
+        sys.stderr.flush()
+        print(compact_line(line, full_path), flush=True)                     # the ONE stdout line (< 4 KB)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -632,7 +632,7 @@ def compact_line(doc, full_path=None):
             more["c4_shard"]["prefiltered_frac"] = _r(c4["prefiltered"]["roofline"]["frac"])
             more["c4_shard"]["prefiltered_identical"] = c4["prefiltered"].get("identical_to_fp32")
     if doc.get("c4_full"):
-        more["c4_full"] = {key: _r(v) for key, v in doc["c4_full"].items() if key in ("rows", "queries_per_s", "ms_per_step", "frac", "identical_to_8_shards")}
+        more["c4_full"] = {key: _r(v) for key, v in doc["c4_full"].items() if key in ("rows", "queries_per_s", "ms_per_step", "frac", "identical_to_8_shards", "planted_recall")}
     hb = doc.get("hbm_regime")
     if hb:
         more["hbm_regime_step_frac"] = {"%dM_nq%d" % (round(e["rows"] / 1e6), e["nq"]): _r(float("%.3g" % e["step_frac_of_hbm_peak"])) for e in hb}
@@ -893,6 +893,38 @@ def main():
                 del b
             line["hbm_regime"] += small
             del big, r4
+            torch.cuda.empty_cache()
+        free, _tot = torch.cuda.mem_get_info(dev)
+        if free > 200 << 30:
+            # C4 at its real row count on ONE GPU: all 365,000,000 rows (186.9 GB) resident, one unsharded scan per 4096-query batch
+            # -- and the same rows as eight sequential shard scans + the strided merge, which is what eight ranks compute
+            n_full, S_ = 8 * C4_ROWS_PER_GPU, 8
+            full = mk(n_full, C4_NQ)
+            el, sc, rf = full.run(2, 1, prep_budget_s=0.0)
+            msf = el / 2 * 1e3
+            idx_off = (4 * C4_NQ * k + 7) // 8 * 8
+            gathered = torch.zeros((S_, idx_off + 8 * C4_NQ * k), dtype=torch.uint8, device=dev)
+            qn_ = full.q_raw / full.q_raw.norm(dim=1, keepdim=True)
+            ops.l2_normalize_rows(full.q_raw, 1e-12, out=full.q)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for r_ in range(S_):
+                lo_, hi_ = sharded.shard_bounds(n_full, S_, r_)
+                out_ = (gathered[r_, : 4 * C4_NQ * k].view(torch.float32).reshape(C4_NQ, k), gathered[r_, idx_off:].view(torch.int64).reshape(C4_NQ, k))
+                ops.ip_topk(full.db[lo_:hi_], full.q, k, row_offset=lo_, out=out_)
+            ms8, mi8 = torch.empty_like(rf[0]), torch.empty_like(rf[1])
+            ops.topk_merge_packed(gathered, S_, C4_NQ, k, idx_off, ms8, mi8)
+            torch.cuda.synchronize(); t8 = (time.perf_counter() - t0) * 1e3
+            fif = rf[1].cpu()
+            line["c4_full"] = {"workload": "C4 at its real size on ONE GPU: %d x 128 fp32 rows (%.1f GB) resident, %d queries, top-%d, one unsharded fp32 scan per batch" % (
+                                   n_full, n_full * 512 / 1e9, C4_NQ, k),
+                               "rows": n_full, "ms_per_step": msf, "queries_per_s": C4_NQ / msf * 1e3,
+                               "frac": roofline(C4_NQ, n_full, k, sc, msf)["frac"], "roofline": roofline(C4_NQ, n_full, k, sc, msf),
+                               "eight_sequential_shards_plus_merge_ms": t8,
+                               "identical_to_8_shards": bool(torch.equal(mi8, rf[1]) and torch.equal(ms8.view(torch.int32), rf[0].view(torch.int32))),
+                               "planted_recall": float(np.mean([len(set(full.planted[j].tolist()) & set(fif[j].tolist())) / 3.0 for j in range(C4_NQ)]))}
+            log("c4_full: %.1f ms per 4096-query batch over 365M rows on one GPU = %.0f q/s (scan %.1f%% of fp32 MFMA peak); 8 shards + merge %.1f ms, identical: %s" % (
+                msf, C4_NQ / msf * 1e3, line["c4_full"]["frac"] * 100, t8, line["c4_full"]["identical_to_8_shards"]))
+            del full, rf, gathered, ms8, mi8, qn_
             torch.cuda.empty_cache()
         # list length: the same C2 shape at other k (lists of 5 / 10 / 16 / 32 entries per lane for k <= 10 / 20 / 32 / 64)
         line["k_sweep"] = []

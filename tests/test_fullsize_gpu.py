@@ -152,6 +152,78 @@ def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
         assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32))
         assert ops.prefilter_flagged(ws) == 0
 
+def test_c4_at_its_real_row_count_on_one_gpu_unsharded_equals_eight_shards_merged(torch_gpu):
+    """C4 at the size BASELINE.json states it: 365,000,000 x 128 fp32 rows (186.9 GB) resident on ONE 288 GB MI355X, 4096 queries,
+    k = 10.  The reference walks the whole database block by block and merges (dbsearch.py:233-243); here ONE unsharded scan of all
+    365M rows must equal -- indices and score bits -- the eight contiguous shards of sharded.shard_bounds scanned one after the other
+    (views of the same tensor, global row = shard offset + local row) and merged by ms_topk_merge_strided, which is exactly what the
+    eight ranks of the sharded run compute.  Also: planted rows on top, lists sorted, the oracle on a query sample over the returned
+    rows, an independent brute force for 64 queries over every row, 1 / 32 queries (HBM-bound regime), and the prefiltered search
+    (rows split in registers: the split image of 365M rows would not fit next to them)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import sharded, synthetic as syn
+    from oracle import oracle as orc
+    n, nq, k, S = 365_000_000, 4096, 10, 8
+    dev = torch.device("cuda", 0)
+    torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info(dev)
+    if free < 200 << 30:
+        pytest.skip("C4 at full size needs 200 GB of free HBM on one GPU (186.9 GB of rows + workspaces); %.0f GB free of %.0f" % (free / 2**30, total / 2**30))
+    db = syn.device_database(n, 0, seed=0, device=dev)
+    assert db.shape == (n, 128) and db.numel() * 4 == 186_880_000_000
+    q = syn.device_database(nq, 0, seed=1, device=dev)
+    gen = torch.Generator(device="cpu"); gen.manual_seed(2)
+    rows = ((torch.arange(nq * 3, dtype=torch.int64) * 2_147_483_629 + 12_345) % n).reshape(nq, 3)      # distinct (a bijection modulo n)
+    assert len(set(rows.reshape(-1).tolist())) == nq * 3
+    near = q.cpu()[:, None, :] + torch.randn((nq, 3, 128), generator=gen) * 0.02
+    near = near / near.norm(dim=2, keepdim=True)
+    db[rows.reshape(-1).to(dev)] = near.reshape(-1, 128).to(dev)
+    # ONE scan over all 365M rows
+    s, i = ops.ip_topk(db, q, k)
+    torch.cuda.synchronize()
+    i_h, s_h = i.cpu().numpy(), s.cpu().numpy()
+    assert all(set(rows[j].tolist()) == set(i_h[j, :3].tolist()) for j in range(nq))
+    assert (np.diff(s_h, axis=1) <= 0).all() and i_h.min() >= 0 and i_h.max() < n
+    assert (i_h > 2**31 - 1).sum() == 0 and (i_h > 300_000_000).any()               # rows of the last shards are found too
+    # eight sequential shard scans (views: no copy) + the strided merge of the gathered blocks, as the eight ranks do it
+    # (each shard's lists are written straight into its packed block [scores | rows], the blocks lie back to back as the all-gather
+    #  leaves them, and ms_topk_merge_strided reads them in place: sharded.PackedExchange's layout)
+    bounds = [sharded.shard_bounds(n, S, r) for r in range(S)]
+    assert bounds[0] == (0, 45_625_000) and bounds[-1][1] == n
+    idx_off = (4 * nq * k + 7) // 8 * 8
+    gathered = torch.zeros((S, idx_off + 8 * nq * k), dtype=torch.uint8, device=dev)
+    for r, (lo, hi) in enumerate(bounds):
+        out = (gathered[r, : 4 * nq * k].view(torch.float32).reshape(nq, k), gathered[r, idx_off:].view(torch.int64).reshape(nq, k))
+        ops.ip_topk(db[lo:hi], q, k, row_offset=lo, out=out)
+    ms, mi = torch.empty_like(s), torch.empty_like(i)
+    ops.topk_merge_packed(gathered, S, nq, k, idx_off, ms, mi)
+    assert torch.equal(mi, i) and torch.equal(ms.view(torch.int32), s.view(torch.int32))
+    del gathered, ms, mi
+    # scores re-computed from the returned rows: bit-exact against the oracle's k-order dot product (query sample)
+    sample = np.r_[0:8, nq - 8:nq]
+    got_rows = db[i[sample].reshape(-1)].cpu().numpy().reshape(len(sample), k, 128)
+    qh = q.cpu().numpy()
+    for a, j in enumerate(sample):
+        s_ref, _ = orc.ip_topk(got_rows[a], qh[j:j + 1], k, order=1)
+        assert np.array_equal(np.sort(s_ref[0].view(np.uint32)), np.sort(s_h[j].view(np.uint32)))
+    # independent brute force over EVERY row for 64 queries (library GEMM, its own summation order: near-tie aware)
+    pick = torch.arange(0, nq, nq // 64, device=dev)[:64]
+    bs, bi = _torch_bruteforce(torch, db, q[pick], k, chunk=1 << 22)
+    assert_topk_equivalent(s_h[pick.cpu().numpy()], i_h[pick.cpu().numpy()], bs.cpu().numpy(), bi.cpu().numpy(), tol=2e-6)
+    del bs, bi
+    # the reference's own regime (a few queries per call): one full pass over 186.9 GB per call
+    for few in (1, 32):
+        sf, jf = ops.ip_topk(db, q[:few], k)
+        assert torch.equal(jf, i[:few]) and torch.equal(sf.view(torch.int32), s[:few].view(torch.int32))
+    # prefiltered search over the fp32 rows (no image), all 4096 lists == the fp32 scan's
+    ws = ops.PrefilterWorkspace(dev).get(n, nq, k)
+    sp, ip_ = ops.ip_topk_prefiltered(db, q, k, 1.0 + 1e-6, workspace=ws, image=None)
+    assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32))
+    del db, ws
+    torch.cuda.empty_cache()
+
+
 def test_c1_real_size_cli_search_on_gpu(tmp_path, golden_dir):
     """C1 at its real size through the CLI on the HIP engine: M0 against the shipped TED example layout
     (66,943 entries), three neighbours planted at the first / last / a middle row."""

@@ -19,12 +19,15 @@ database grows N-fold; the N = 1 point of that curve is the `c4_shard` entry of 
 `--rows R` overrides either default with R total rows sharded over the ranks (strong scaling).
 
 The top-level line is the fp32 scan (ms_ip_topk_prepare / _scan / _finish): the reference's own arithmetic, data-independent.  The
-PREFILTERED search (ms_ip_topk_prefiltered: the rows scanned once with bf16 matrix instructions over the split-bf16 image built
-when the database became resident, the best 2k rows per query re-scored with the exact fp32 chain, the answer proved complete per
-query, an exact fp32 pass for the queries whose proof failed) -- what the driver runs for more than 64 queries, bit-identical
-results -- is the named block `prefiltered` beside it, with its own dtype, roofs and traffic; `--no-prefilter` skips those blocks.
+PREFILTERED search (ms_ip_topk_prefiltered: the rows scanned once with fp16 matrix instructions over the fp16 image built when the
+database became resident -- MS_PF_F16X2: fp16 rows x split fp16 queries, 2 instructions per 16 dimensions, 256 B per row -- the best
+2k rows per query re-scored with the exact fp32 chain, the answer proved complete per query, an exact fp32 pass for the queries whose
+proof failed) -- what the driver runs for more than 64 queries, bit-identical results -- is the named block `prefiltered` beside it,
+with its own dtype, roofs and traffic; `--no-prefilter` skips those blocks; MS_BENCH_PF_FORMAT=f16x1|bf16x3 times the other arithmetics.
 
-One JSON line is printed by rank 0 (contract in the task statement), with
+ONE JSON line under 4 KB is printed on stdout by rank 0 (contract in the task statement: metric, value, ..., `roofline`, a short
+`prefiltered` summary, `cpu_baseline`, headline numbers of the other entries under `more`); the FULL document -- every block below --
+goes to bench_full.json beside this file and to stderr.  The blocks:
   roofline      dominant kernel of the top-level step, the fp32 scan launch (ms_scan_loader_kernel; ms_scan_kernel below 3 query
                 tiles): algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the launch against the fp32
                 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic bytes (512 B per row) against the 8 TB/s HBM peak; both
@@ -89,29 +92,45 @@ def small_batch_note(nq, ops=None):
             "scan_ms = HIP events around that call (a separate loop) = " + what)
 
 
-def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=False):
+PF_FORMATS = {   # name -> (matrix instructions per 16 dimensions, image bytes per row, matrix instruction, dtype label)
+    "f16x2": (2, 256.0, "v_mfma_f32_32x32x16_f16", "f16x2 scan (fp16 rows x split fp16 queries) + f32 re-score"),
+    "f16x1": (1, 256.0, "v_mfma_f32_32x32x16_f16", "f16x1 scan (fp16 rows x fp16 queries) + f32 re-score"),
+    "bf16x3": (3, 512.0, "v_mfma_f32_32x32x16_bf16", "bf16x3-split scan + f32 re-score"),
+}
+
+
+def pf_format_name(ops, image):
+    return {ops.PF_F16X2: "f16x2", ops.PF_F16X1: "f16x1", ops.PF_BF16X3: "bf16x3"}[image.format]
+
+
+def roofline(nq, rows, k, scan_ms, step_ms, prefiltered=None):
     """Both roofs for one scan launch over `rows` rows; the binding one is `frac`.
-    prefiltered: the scan of ms_ip_topk_prefiltered over the split-bf16 image issues 3 bf16 matrix instructions per 16 dimensions
-    (hi.hi, hi.lo, lo.hi): its matrix roof is 3 x the algorithmic flops over the dense bf16 peak, its memory roof the one read of
-    the image (512 B per row, like the fp32 rows)."""
+    prefiltered (a PF_FORMATS name): the scan of ms_ip_topk_prefiltered over the image issues m 16-bit matrix instructions per 16
+    dimensions (f16x2: rowh.qh + rowh.ql; f16x1: rowh.qh; bf16x3: hi.hi, hi.lo, lo.hi): its matrix roof is m x the algorithmic flops
+    over the dense 16-bit matrix peak (2.5 PFLOP/s for fp16 and bf16 alike), its memory roof the one read of the image (256 B per
+    row for the fp16 image, 512 B for the split-bf16 one)."""
     flops = 2.0 * 128 * nq * rows
     bytes_ = 512.0 * rows
     t = scan_ms * 1e-3
     mfma_frac, hbm_frac = flops / t / MFMA_F32_PEAK, bytes_ / t / HBM_PEAK
     if prefiltered:
-        executed = 3.0 * flops
+        m, bpr, instr, _ = PF_FORMATS[prefiltered]
+        bytes_ = bpr * rows
+        hbm_frac = bytes_ / t / HBM_PEAK
+        executed = float(m) * flops
         bf16_frac = executed / t / MFMA_BF16_PEAK
-        matrix_bound = executed / MFMA_BF16_PEAK >= bytes_ / HBM_PEAK           # from 208 queries
+        matrix_bound = executed / MFMA_BF16_PEAK >= bytes_ / HBM_PEAK
         if matrix_bound:
             roof = {"bound": "mfma", "achieved": executed / t / 1e12, "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s", "frac": bf16_frac,
                     "step_frac": executed / (step_ms * 1e-3) / MFMA_BF16_PEAK}
         else:
             roof = {"bound": "hbm", "achieved": bytes_ / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": hbm_frac,
                     "step_frac": bytes_ / (step_ms * 1e-3) / HBM_PEAK}
-        roof.update({"traffic": None, "kernel": "ms_scan_pf2_kernel (split-bf16 image; ms_rescore_kernel makes the scores exact)",
-                     "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "split_bf16_mfma_frac": bf16_frac,
+        roof.update({"traffic": None, "kernel": "ms_scan_pf16_kernel (%s)" % prefiltered if prefiltered != "bf16x3" else "ms_scan_pf2_kernel (bf16x3)",
+                     "kernel_ms": scan_ms, "hbm_frac": hbm_frac, "matrix_16bit_frac": bf16_frac, "format": prefiltered, "matrix_instruction": instr,
+                     "matrix_instructions_per_16_dims": m, "image_bytes_per_row": bpr,
                      "algorithmic_tflops": flops / t / 1e12, "rows_per_launch": rows, "algorithmic_bytes_per_launch": bytes_,
-                     "algorithmic_flops_per_launch": flops, "executed_bf16_flops_per_launch": executed,
+                     "algorithmic_flops_per_launch": flops, "executed_16bit_flops_per_launch": executed,
                      "note": "see notes.prefiltered_roofline"})
         return roof
     if nq >= 39:
@@ -192,7 +211,10 @@ class SearchBench:
         self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_total // self.world, self.nq, self.k)
         if self.prefilter and self.image is None:
             self.row_norm_bound = float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)
-            self.image = ops.pf_build_image(self.db)
+            self.image = ops.pf_build_image(self.db, row_norm_bound=self.row_norm_bound)     # (the driver's default format: MS_PF_F16X2)
+            fmt_env = os.environ.get("MS_BENCH_PF_FORMAT")                                    # A/B runs: f16x1 over the same image
+            if fmt_env:
+                self.image = self.image.as_format({"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1, "bf16x3": ops.PF_BF16X3}[fmt_env])
         self.ws = self.torch.empty_like((ops.PrefilterWorkspace if self.prefilter else ops.TopKWorkspace)(dev).get(self.n_local, self.nq, self.k))
 
     def variant(self, prefilter):
@@ -428,10 +450,10 @@ def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
             ops.ip_topk_prefiltered_stage("finish", unit, q, k, pws, out=(ps, pi), **pkw)
 
         pms, pscan = _timed_stages(torch, pstep, 40)
-        out["prefiltered"] = {"ms_per_step": pms, "queries_per_s": nq / pms * 1e3, "dtype": "bf16x3-split scan + f32 re-score",
+        out["prefiltered"] = {"ms_per_step": pms, "queries_per_s": nq / pms * 1e3, "dtype": PF_FORMATS[pf_format_name(ops, img)][3],
                               "identical_to_fp32": bool(torch.equal(pi, out_i) and torch.equal(ps.view(torch.int32), out_s.view(torch.int32))),
-                              "exact_pass_queries": ops.prefilter_flagged(pws), "roofline": roofline(nq, n, k, pscan, pms, prefiltered=True)}
-        attach_committed_traffic(out["prefiltered"]["roofline"], "r04_pf_c3_pmc.json")
+                              "exact_pass_queries": ops.prefilter_flagged(pws), "roofline": roofline(nq, n, k, pscan, pms, prefiltered=pf_format_name(ops, img))}
+        attach_committed_traffic(out["prefiltered"]["roofline"], "r05_pf_c3_pmc.json")
         log("c3_search prefiltered: %.3f ms per batch (scan %.3f ms), identical: %s, exact-pass queries: %d" % (
             pms, pscan, out["prefiltered"]["identical_to_fp32"], out["prefiltered"]["exact_pass_queries"]))
         state.update(image=img, pws=pws)
@@ -779,11 +801,12 @@ def main():
         torch.cuda.synchronize()
         el, sc, rp = bp.run(steps_, warm_, prep_budget_s=prep_s)
         ms = el / steps_ * 1e3
-        blk = {"ms_per_step": ms, "queries_per_s": bp.nq / ms * 1e3, "dtype": "bf16x3-split scan + f32 re-score",
+        fmt = pf_format_name(ops, bp.image)
+        blk = {"ms_per_step": ms, "queries_per_s": bp.nq / ms * 1e3, "dtype": PF_FORMATS[fmt][3],
                "identical_to_fp32": bool(torch.equal(rp[1], res_fp32[1]) and torch.equal(rp[0].view(torch.int32), res_fp32[0].view(torch.int32))),
                "exact_pass_queries": ops.prefilter_flagged(bp.ws) if world == 1 else None,
-               "split_image_bytes": int(bp.image.numel()),
-               "roofline": roofline(bp.nq, bp.n_local, bp.k, sc, ms, prefiltered=True),
+               "image_bytes": int(bp.image.numel()),
+               "roofline": roofline(bp.nq, bp.n_local, bp.k, sc, ms, prefiltered=fmt),
                "note": "see notes.prefiltered"}
         if pmc is not None:
             attach_committed_traffic(blk["roofline"], pmc)
@@ -791,7 +814,7 @@ def main():
         return blk
 
     c2 = (n_total, nq, k, world) == (1_000_000, 256, 10, 1)
-    pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r04_pf_c2_pmc.json" if c2 else None) if use_pf else None
+    pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r05_pf_c2_pmc.json" if c2 else None) if use_pf else None
 
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
@@ -870,7 +893,7 @@ def main():
                 attach_committed_traffic(line["c4_shard"]["roofline"], "r04_c4_pmc.json")
             log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (fp32 scan %.1f ms = %.1f%% of fp32 MFMA peak)" % (ms4, C4_NQ / ms4 * 1e3, sc, line["c4_shard"]["roofline"]["frac"] * 100))
             if use_pf:
-                line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r04_pf_c4_pmc.json" if k == 10 else None)
+                line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r05_pf_c4_pmc.json" if k == 10 else None)
                 p4 = line["c4_shard"]["prefiltered"]
                 log("c4_shard prefiltered: %.1f ms per batch = %.0f q/s, scan %.1f ms, identical: %s" % (p4["ms_per_step"], p4["queries_per_s"], p4["roofline"]["kernel_ms"], p4["identical_to_fp32"]))
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows
@@ -953,12 +976,12 @@ def main():
             q_unit = bench.q_raw / bench.q_raw.norm(dim=1, keepdim=True)
             line["cpu_baseline"] = cpu_baseline(bench.db, q_unit, k, n_total, extras_sd, extras_coords)
         line["notes"] = {
-            "prefiltered": "ms_ip_topk_prefiltered over the split-bf16 image built when the database became resident (512 B per row next to the "
-                           "fp32 rows); the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, an exact "
+            "prefiltered": "ms_ip_topk_prefiltered over the image built when the database became resident (fp16 rows, 256 B per row next to the "
+                           "fp32 rows; MS_PF_F16X2: 2 fp16 matrix instructions per 16 dimensions); the 2k best rows per query re-scored with the exact fp32 chain, per-query proof of completeness, an exact "
                            "fp32 pass for the queries whose proof failed (exact_pass_queries of them); results bit-identical to the fp32 scan "
                            "(tests/test_prefilter_gpu.py)",
-            "prefiltered_roofline": "achieved / frac (matrix-bound shapes) count the flops the launch EXECUTES: 3 bf16 matrix instructions per 16 "
-                                    "dimensions = 3 x the algorithmic flops, against the dense bf16 matrix peak -- the roof of this arithmetic; "
+            "prefiltered_roofline": "achieved / frac (matrix-bound shapes) count the flops the launch EXECUTES: m 16-bit matrix instructions per 16 "
+                                    "dimensions = m x the algorithmic flops (f16x2: 2, f16x1: 1, bf16x3: 3), against the dense 16-bit matrix peak -- the roof of this arithmetic; "
                                     "algorithmic_tflops is the un-tripled figure (it may exceed the fp32 matrix peak: this is not fp32 matrix work)",
             "traffic": "roofline.traffic = HBM bytes per launch from the rocprofv3 --pmc passes named in traffic_source (gfx950 corrections: "
                        "tools/pmc_to_json.py); counters need the profiler, so they are not collected inside this run",

@@ -112,42 +112,61 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
  *
  * Replaces index.search of dbsearch.py:234-242 (MS_MODE_IP_PRENORM / MS_MODE_IP_NORMQ) and, on rows normalised once,
  * search_query_against_db of dbsearch.py:75-81 (MS_MODE_COSINE_UNIT) for batches of more than 64 queries, k <= MS_PREFILTER_MAX_K and
- * databases of >= 65,536 rows.  The rows are scanned once with bf16 matrix instructions on split operands (hi + lo halves of
- * every float), which gives every score to within 2.5e-4 |row| |q|; the 2k-4k best rows per query by that score are re-scored
+ * databases of >= 65,536 rows.  The rows are scanned once with 16-bit matrix instructions on an image of the database (fp16 rows
+ * against split fp16 queries, or bf16 hi + lo halves of both), which gives every score to within E |row| |q| (E = 2.5e-4 .. 1.05e-3
+ * by format, below); the 2k-4k best rows per query by that score are re-scored
  * with the exact fp32 chain (ms_ip_topk's own arithmetic, from the fp32 rows) and the best k of them are returned -- after a
  * PER-QUERY proof that no other row can belong to the answer (the k-th exact score exceeds the last kept approximate score by
  * more than the error bound).  Queries whose proof fails (dozens of rows within the error bound of their k-th best: families of
  * near-duplicates) are gathered into a dense batch on the device and an exact fp32 scan, queued behind on the same stream, runs
  * for THOSE queries only: always exact, never an approximation, and a clustered query costs only itself.
  *
- *   pf_image         the split image of db: ms_pf_build_image, made once when the database becomes resident (512 B per row next to
- *                    the fp32 rows, which stay: the re-scoring and the exact pass read them).  The scan then streams MFMA-ready
- *                    operands and converts nothing.  NULL: the rows are split in registers instead (no second copy of anything;
- *                    about 2.5x slower; inner-product modes only -- MS_MODE_COSINE_UNIT without an image is ms_ip_topk).
+ *   pf_image / pf_format   an MFMA-ready image of db made once, when the database becomes resident (ms_pf_build_image), next to the
+ *                    fp32 rows -- which stay: the re-scoring and the exact pass read them.  The scan then streams operands and
+ *                    converts nothing.  Three arithmetics, all with the same exact results (E = the bound on |approximate - exact|
+ *                    the proof uses, in units of |row| |q|; ms_pf_err_coef):
+ *                      MS_PF_BF16X3  rows AND queries split into bf16 hi + lo, 3 matrix instructions per 16 dimensions, 512 B per
+ *                                    row, E = 2.5e-4 (round 4);
+ *                      MS_PF_F16X2   rows rounded to fp16, queries split into fp16 hi + lo, 2 matrix instructions per 16
+ *                                    dimensions, 256 B per row, E = 5.5e-4 (round 5; the default of the Python driver);
+ *                      MS_PF_F16X1   the SAME image as MS_PF_F16X2, the query's hi part only: 1 matrix instruction per 16
+ *                                    dimensions, E = 1.05e-3 (more queries fail their proof on clustered data).
+ *                    pf_format of a search must be the arithmetic the image was built for (F16X2 and F16X1 share one image; the
+ *                    fp16 image carries a trailer the scan checks: a mismatch traps instead of answering).
+ *                    pf_image NULL: the rows are split in registers instead (bf16 x 3; no second copy of anything; about 2.5x
+ *                    slower; inner-product modes only -- MS_MODE_COSINE_UNIT without an image is ms_ip_topk); pf_format is ignored.
  *   lengths / qlen / mincov   MS_MODE_COSINE_UNIT: the length mask of dbsearch.py:76 (NULL, NULL: none); NULL in the other modes.
  *   row_norm_bound   an upper bound on the L2 norm of every row of db (1.0 + 1e-6 for unit rows, as dbfname_IP and
  *                    MS_MODE_COSINE_UNIT hold; 1 / min(ms_row_inv_norms) otherwise); <= 0, not finite (a database with non-finite
  *                    rows has no bound) or shapes outside the above: the call is ms_ip_topk.  Queries with non-finite elements
- *                    fail their proof and get the exact pass.
+ *                    (fp16 formats: or a norm outside [2^-40, 2^40]) fail their proof and get the exact pass.
+ *                    ms_pf_build_image takes it too: the fp16 image stores row * 2^sr with sr chosen from it (components below
+ *                    2^15; outside [2^-40, 2^40] the fp16 formats are declined with MS_ERR_RANGE); MS_PF_BF16X3 ignores it.
  * Workspace: ms_ip_topk_prefiltered_workspace_bytes.  _prepare / _scan / _finish: its three stages as for ms_ip_topk
- * (queries + sample pass; the one scan launch; merge + exact re-scoring + the exact pass over the flagged queries). */
+ * (queries + sample pass; the one scan launch; merge + exact re-scoring + the exact pass over the flagged queries).
+ * ABI note: ms_version() >= 200 (round 5) -- ms_pf_image_bytes / ms_pf_build_image gained `pf_format` (+ row_norm_bound), the four
+ * search entry points gained `pf_format` behind `pf_image`; version 100 callers must be rebuilt (merizo_search_amd/_lib.py checks). */
 #define MS_PREFILTER_MAX_K 48
-size_t ms_pf_image_bytes(int64_t n);
-int ms_pf_build_image(const float *db, int64_t n, void *pf_image, ms_stream_t stream);
+#define MS_PF_BF16X3 0
+#define MS_PF_F16X2 1
+#define MS_PF_F16X1 2
+size_t ms_pf_image_bytes(int64_t n, int pf_format);
+int ms_pf_build_image(const float *db, int64_t n, int pf_format, float row_norm_bound, void *pf_image, ms_stream_t stream);
+float ms_pf_err_coef(int pf_format);      /* E of the format, per unit of |row| |q|; < 0: unknown format */
 size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k);
-int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k,
-                           int mode, const float *lengths, const float *qlen, float mincov, float row_norm_bound,
+int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int pf_format, int64_t n, int64_t row_offset, const float *q, int nq,
+                           int k, int mode, const float *lengths, const float *qlen, float mincov, float row_norm_bound,
                            float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int pf_format, int64_t n, const float *q, int nq, int k, int mode,
                                    const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                    size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int pf_format, int64_t n, const float *q, int nq, int k, int mode,
                                 const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                 size_t workspace_bytes, ms_stream_t stream);
-int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq,
-                                  int k, int mode, const float *lengths, const float *qlen, float mincov, float row_norm_bound,
-                                  float *out_scores, int64_t *out_idx, void *workspace, size_t workspace_bytes,
-                                  ms_stream_t stream);
+int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int pf_format, int64_t n, int64_t row_offset, const float *q,
+                                  int nq, int k, int mode, const float *lengths, const float *qlen, float mincov,
+                                  float row_norm_bound, float *out_scores, int64_t *out_idx, void *workspace,
+                                  size_t workspace_bytes, ms_stream_t stream);
 /* Diagnostics (tests; synchronises the device): what the last prefiltered search on this workspace left behind -- *flagged =
  * how many of its queries needed the exact pass (0: every answer was proved), *gate_value == *last_epoch iff any did. */
 int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned int *last_epoch, unsigned int *flagged);

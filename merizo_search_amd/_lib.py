@@ -35,6 +35,10 @@ _int = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
 
+ABI_VERSION = 200
+# prefilter image formats (include/merizo_search_amd.h)
+PF_BF16X3, PF_F16X2, PF_F16X1 = 0, 1, 2
+
 # name -> (restype, argtypes); exactly the symbols include/merizo_search_amd.h declares
 SIGNATURES = {
     "ms_version": (_int, []),
@@ -51,13 +55,14 @@ SIGNATURES = {
     "ms_ip_topk_prepare": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_scan": (_int, [_vp, _i64, _vp, _int, _int, _int, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
     "ms_ip_topk_finish": (_int, [_i64, _i64, _int, _int, _vp, _vp, _vp, _sz, _vp]),
-    "ms_pf_image_bytes": (_sz, [_i64]),
-    "ms_pf_build_image": (_int, [_vp, _i64, _vp, _vp]),
+    "ms_pf_image_bytes": (_sz, [_i64, _int]),
+    "ms_pf_build_image": (_int, [_vp, _i64, _int, _f, _vp, _vp]),
+    "ms_pf_err_coef": (_f, [_int]),
     "ms_ip_topk_prefiltered_workspace_bytes": (_sz, [_i64, _int, _int]),
-    "ms_ip_topk_prefiltered": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_prepare": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_scan": (_int, [_vp, _vp, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
-    "ms_ip_topk_prefiltered_finish": (_int, [_vp, _vp, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_prepare": (_int, [_vp, _vp, _int, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_scan": (_int, [_vp, _vp, _int, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
+    "ms_ip_topk_prefiltered_finish": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "ms_debug_prefilter_state": (_int, [_vp, _vp, _vp, _vp]),
     "ms_debug_prefilter_lists": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
@@ -103,6 +108,9 @@ def load() -> ctypes.CDLL:
             raise MerizoHipError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args
+    # the ABI this module binds: 200 = pf_format in the prefilter entry points (an older library would take shifted arguments)
+    if lib.ms_version() != ABI_VERSION:
+        raise MerizoHipError(f"{LIB_PATH} reports ABI version {lib.ms_version()}, this package binds {ABI_VERSION}: rebuild it (make -C {CSRC})")
     _lib = lib
     return lib
 

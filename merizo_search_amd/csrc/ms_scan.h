@@ -67,7 +67,8 @@ struct ScanParams {
                             // the caller re-scores the survivors exactly: ms_ip_topk_prefiltered)
     const ScanDevPlan *dev_plan = nullptr;   // ms_scan_kernel only: nq, the streams and the grid come from device memory (exact pass
                                              // over the flagged queries of a prefiltered search); workgroups past its grid return at once
-    const void *pf_image = nullptr;   // prefilter, ms_scan_pf.h: the split-bf16 image of db (ms_pf_build_image), or NULL (split in registers)
+    const void *pf_image = nullptr;   // prefilter, ms_scan_pf.h / ms_scan_pf16.h: the image of db (ms_pf_build_image), or NULL (split in registers)
+    int pf_format = 0;                // ... and its arithmetic: MS_PF_BF16X3 (32-row tiles), MS_PF_F16X2 / MS_PF_F16X1 (64-row tiles)
     int qpw = 1;                      // ... and the waves per workgroup of that kernel, one query tile each, in fours (1: 4 waves, 2: 8)
     const uint32_t *gate = nullptr;   // NULL, or: the launch does nothing unless *gate == gate_epoch (the exact pipeline behind a
     uint32_t gate_epoch = 0;          // prefiltered search runs only when the prefilter could not prove its answer)

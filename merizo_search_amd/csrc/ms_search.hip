@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void ms_prepare_queries_kernel(const float *q,
 
 #include "ms_scan.h"
 #include "ms_scan_pf.h"
+#include "ms_scan_pf16.h"
 
 // ------------------------------------------------------------------ partial merge ------
 // One workgroup per query merges its P partial lists (each sorted best-first, rank-major
@@ -389,9 +390,9 @@ struct PfCompact {
     int cus, nq;
 };
 __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
-                                                        const int64_t *ai, int64_t row_offset, float err_coef, const float *lengths,
+                                                        const int64_t *ai, int64_t row_offset, float err_coef, int fp16_range, const float *lengths,
                                                         const float *qlen, float mincov, float *out_s, int64_t *out_i, uint32_t *flag,
-                                                        float *exact_lb, const PfCompact cp) {
+                                                        const PfCompact cp) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -447,9 +448,12 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
     __syncthreads();
     __shared__ int slot_s;
     if (lane == 0) {
-        exact_lb[q] = kth;      // k rows score at least this: the bound the exact scan starts from, should it have to run (-inf: none)
+        // (kth: k rows score at least this -- the bound the exact scan starts from, should it have to run (-inf: none): lb_c below)
         // (a list that is not full cannot happen on a database of >= 65,536 rows unless rows were lost to a bound: no proof then either)
-        const bool flagged = !full || !(kth > a_last + err_coef * qnorm);
+        // (fp16 formats: the scan scales every query into the fp16 range by a power of two it clamps at 2^+-60 -- a query whose norm is
+        //  outside [2^-40, 2^40] is not covered by the error bound: no proof)
+        const bool in_range = !fp16_range || (qnorm >= 9.094947e-13f && qnorm <= 1.0995116e12f);
+        const bool flagged = !full || !in_range || !(kth > a_last + err_coef * qnorm);
         flag[q] = flagged ? 1u : 0u;
         int slot = -1;
         if (flagged) {
@@ -690,7 +694,8 @@ int pick_kl(int k_pass) {
 }
 
 // qpw > 0: the plan of the split-image prefilter scan (ms_scan_pf.h): 4 waves x qpw query tiles per workgroup, one workgroup per CU
-ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
+// tile_rows: rows per tile of that kernel's image (32: split-bf16, 64: fp16); streams are whole tiles
+ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows = 32) {
     ScanPlan pl;
     pl.nq_real = nq;
     pl.qpw = qpw;
@@ -710,11 +715,13 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
         const int group_tiles = 4 * qpw;   // query tiles per workgroup
         pl.n_qgroups = (pl.n_qtiles + group_tiles - 1) / group_tiles;
         pl.nq_pad = pl.n_qgroups * group_tiles * 32;
+        const int64_t big_tiles = (n + tile_rows - 1) / tile_rows;
         int64_t want = (int64_t)cus / pl.n_qgroups;
         if (want < 1) want = 1;
-        if (want > tiles) want = tiles > 0 ? tiles : 1;
-        tiles_per_stream = (tiles + want - 1) / want;
-        pl.rows_per_stream = (int)((tiles_per_stream > 0 ? tiles_per_stream : 1) * 32);
+        if (want > big_tiles) want = big_tiles > 0 ? big_tiles : 1;
+        const int64_t big_per_stream = (big_tiles + want - 1) / want;
+        tiles_per_stream = big_per_stream * (tile_rows / 32);           // (in 32-row units: the sample-size rule below)
+        pl.rows_per_stream = (int)((big_per_stream > 0 ? big_per_stream : 1) * tile_rows);
         pl.n_streams = (int)((n + pl.rows_per_stream - 1) / pl.rows_per_stream);
         if (pl.n_streams < 1) pl.n_streams = 1;
         pl.n_sgroups = pl.n_streams;
@@ -742,6 +749,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0) {
     }
     if (tiles_per_stream < 8 * (int64_t)pl.prepass_tiles) pl.prepass_tiles = (int)(tiles_per_stream / 8);
     if (tiles_per_stream < 12 || k > 64 || nq < sample_min_queries_setting()) pl.prepass_tiles = 0;   // short streams / few queries: few insertions anyway
+    if (qpw > 0 && tile_rows == 64) pl.prepass_tiles = (pl.prepass_tiles + 1) / 2;                     // (counted in the kernel's own tiles)
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
     pl.off_inv = off;     off += ms_align_up((size_t)(n > 0 ? n : 1) * sizeof(float), 256);
@@ -778,7 +786,13 @@ int check_search_args(const float *db, int64_t n, const float *q, int nq, int k,
 }
 
 int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
-    if (sp.prefilter && sp.pf_image != nullptr) {                  // the prefilter's scan over the split image
+    if (sp.prefilter && sp.pf_image != nullptr && sp.pf_format != MS_PF_BF16X3) {      // the prefilter's scan over the fp16 image
+        if (pick_kl(sp.k) == 5) return ms_launch_scan_pf16_kl5(pl, sp, st);
+        if (pick_kl(sp.k) == 10) return ms_launch_scan_pf16_kl10(pl, sp, st);
+        if (pick_kl(sp.k) == 16) return ms_launch_scan_pf16_kl16(pl, sp, st);
+        return ms_launch_scan_pf16_kl32(pl, sp, st);
+    }
+    if (sp.prefilter && sp.pf_image != nullptr) {                  // the prefilter's scan over the split-bf16 image
         if (pick_kl(sp.k) == 5) return ms_launch_scan_pf2_kl5(pl, sp, st);
         if (pick_kl(sp.k) == 10) return ms_launch_scan_pf2_kl10(pl, sp, st);
         if (pick_kl(sp.k) == 16) return ms_launch_scan_pf2_kl16(pl, sp, st);
@@ -876,7 +890,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
     sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
-    sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0; sp->pf_image = nullptr; sp->qpw = pl.qpw;
+    sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0; sp->pf_image = nullptr; sp->pf_format = 0; sp->qpw = pl.qpw;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -894,7 +908,7 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
     ScanParams s0 = *sp;
     s0.max_tiles = pl.prepass_tiles;
     s0.lb_s = nullptr;
-    int rc = (s0.prefilter && s0.pf_image != nullptr) ? ms_launch_sample_pf2(pl, s0, st)
+    int rc = (s0.prefilter && s0.pf_image != nullptr) ? (s0.pf_format != MS_PF_BF16X3 ? ms_launch_sample_pf16(pl, s0, st) : ms_launch_sample_pf2(pl, s0, st))
              : ((pl.qwb == 4 && loader_wave_setting()) ? ms_launch_sample_loader(pl, s0, st) : launch_scan(pl, s0, st));
     if (rc) return rc;
     float *lb = reinterpret_cast<float *>(ws + pl.off_lb_s);
@@ -957,7 +971,7 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
 
 extern "C" {
 
-int ms_version(void) { return 100; }
+int ms_version(void) { return 200; }      // 200: pf_format in the prefilter entry points (round 5)
 const char *ms_last_error(void) { return ms_err_buf; }
 
 int ms_device_count(void) {
@@ -1141,7 +1155,12 @@ struct PfLayout {
     int kp, exact_grid_max, exact_P_max;
     bool ok;
 };
-PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image) {
+bool pf_format_ok(int f) { return f == MS_PF_BF16X3 || f == MS_PF_F16X2 || f == MS_PF_F16X1; }
+float pf_err_coef(bool image, int format) {
+    if (!image || format == MS_PF_BF16X3) return MS_PF_ERR;
+    return format == MS_PF_F16X2 ? MS_PF_ERR_F16X2 : MS_PF_ERR_F16X1;
+}
+PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image, int format = MS_PF_BF16X3) {
     PfLayout L;
     const int cus = cu_count_cached();
     L.kp = pf_list_len(k);
@@ -1154,7 +1173,7 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image) {
     if (!L.ok) { L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0; return L; }
     // two query tiles per wave (8 per workgroup) from 5 query tiles, while the lists leave room for it
     const int qpw = image ? ((L.exact.n_qtiles >= 5 && L.kp <= 32) ? 2 : 1) : 0;
-    L.pf = make_plan(n, nq, L.kp, cus, qpw);
+    L.pf = make_plan(n, nq, L.kp, cus, qpw, (image && format != MS_PF_BF16X3) ? 64 : 32);
     // the exact pass runs over 1 .. nq queries, decomposed on the device: the launch grid and the merge's LDS cover every case
     size_t lists_max = 0;        // (its partial lists: nq_pad * P entries per rank, whichever decomposition the device picks)
     for (int qt = 1; qt <= L.exact.n_qtiles; ++qt) {
@@ -1163,6 +1182,11 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image) {
         if (d.grid > L.exact_grid_max) L.exact_grid_max = d.grid;
         if (d.P > L.exact_P_max) L.exact_P_max = d.P;
         if ((size_t)d.nq_pad * d.P > lists_max) lists_max = (size_t)d.nq_pad * d.P;
+    }
+    if (L.exact_P_max > 256) {       // the merge behind the exact pass stages <= 256 lists per query (a device with more than 256 CUs): ms_ip_topk
+        L.ok = false;
+        L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0;
+        return L;
     }
     size_t off = L.pf.total > L.exact.total ? L.pf.total : L.exact.total;
     const int nq_pad = L.pf.nq_pad > L.exact.nq_pad ? L.pf.nq_pad : L.exact.nq_pad;
@@ -1179,13 +1203,14 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image) {
     L.total = off;
     return L;
 }
-int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+int pf_run(int stages, const float *db, const void *image, int format, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
            const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores, int64_t *out_idx,
            void *workspace, size_t workspace_bytes, hipStream_t st) {
     int rc = check_search_args(db, n, q, nq, k, mode, nullptr, lengths, qlen);
     if (rc) return rc;
     if (mode == MS_MODE_COSINE_RAW) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: MS_MODE_COSINE_RAW is not served (normalise the rows once: MS_MODE_COSINE_UNIT)");
-    const PfLayout L = pf_layout(n, nq, k, mode, image != nullptr);
+    if (image != nullptr && !pf_format_ok(format)) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: unknown pf_format %d", format);
+    const PfLayout L = pf_layout(n, nq, k, mode, image != nullptr, format);
     if (workspace == nullptr || workspace_bytes < L.total)
         MS_FAIL(MS_ERR_WORKSPACE, "ms_ip_topk_prefiltered: workspace %zu < %zu bytes", workspace_bytes, L.total);
     char *blk = L.ok && row_norm_bound > 0.0f && row_norm_bound < INFINITY ? sync_block_for(workspace) : nullptr;
@@ -1201,13 +1226,13 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
     if (stages & 1) {
         rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, lengths, qlen, mincov, ws, st, &sp);
         if (rc) return rc;
-        sp.prefilter = 1; sp.pf_image = image;
+        sp.prefilter = 1; sp.pf_image = image; sp.pf_format = format;
         rc = run_prepass(pl, &sp, nq, ws, st);
         if (rc) return rc;
         if (sp.hist != nullptr) hist_mark_clean(workspace, n, nq, L.kp);
     } else {
         fill_scan_params(pl, db, n, q, nq, nullptr, lengths, qlen, mincov, ws, mode, &sp);
-        sp.prefilter = 1; sp.pf_image = image;
+        sp.prefilter = 1; sp.pf_image = image; sp.pf_format = format;
         if (pl.prepass_tiles > 0) {
             sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
             if (hist_setting()) {
@@ -1234,7 +1259,6 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
         const uint32_t epoch = next_epoch();
         const ScanPlan &px = L.exact;
         uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.off_flag);
-        float *exact_lb = reinterpret_cast<float *>(ws + px.off_lb_s);
         float *qn_c = reinterpret_cast<float *>(ws + L.off_qn_c), *lb_c = reinterpret_cast<float *>(ws + L.off_lb_c);
         float *qlen_c = reinterpret_cast<float *>(ws + L.off_qlen_c);
         int *qmap = reinterpret_cast<int *>(ws + L.off_qmap);
@@ -1242,8 +1266,10 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
         PfCompact cp;
         cp.qn_c = qn_c; cp.lb_c = lb_c; cp.qlen_c = qlen_c; cp.qmap = qmap; cp.dp = dp; cp.gate = gate; cp.epoch = epoch; cp.n = n;
         cp.cus = cu_count_cached(); cp.nq = nq;
-        hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, MS_PF_ERR * row_norm_bound,
-                           lengths, qlen, mincov, out_scores, out_idx, flag, exact_lb, cp);
+        MS_HIP_CHECK(hipMemsetAsync(gate + 4, 0, 2 * sizeof(uint32_t), st));      // slot counter + ticket: zero whatever an aborted launch left
+        hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, pf_err_coef(image != nullptr, format) * row_norm_bound,
+                           (image != nullptr && format != MS_PF_BF16X3) ? 1 : 0,
+                           lengths, qlen, mincov, out_scores, out_idx, flag, cp);
         MS_LAUNCH_CHECK("ms_rescore_kernel");
         // The exact pass, for the flagged queries ONLY (the reference's semantics are per query: dbsearch.py:234-242): an fp32 scan
         // and a merge over the compacted batch, decomposed on the device (ScanDevPlan), both returning at once when no query was
@@ -1271,48 +1297,61 @@ int pf_run(int stages, const float *db, const void *image, int64_t n, int64_t ro
 }
 }  // namespace
 
-size_t ms_pf_image_bytes(int64_t n) { return n < 0 ? 0 : (size_t)((n + 31) / 32) * 16384; }
+size_t ms_pf_image_bytes(int64_t n, int pf_format) {
+    if (n < 0 || !pf_format_ok(pf_format)) return 0;
+    if (pf_format == MS_PF_BF16X3) return (size_t)((n + 31) / 32) * 16384;
+    return (size_t)((n + 63) / 64) * 16384 + 256;          // (+ the trailer the scan checks: magic, scale exponent, n)
+}
+float ms_pf_err_coef(int pf_format) { return pf_format_ok(pf_format) ? pf_err_coef(true, pf_format) : -1.0f; }
 
-int ms_pf_build_image(const float *db, int64_t n, void *image, ms_stream_t stream) {
-    if (n < 0 || (n > 0 && (db == nullptr || image == nullptr))) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: bad arguments");
+int ms_pf_build_image(const float *db, int64_t n, int pf_format, float row_norm_bound, void *image, ms_stream_t stream) {
+    if (!pf_format_ok(pf_format)) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: unknown pf_format %d", pf_format);
+    if (n < 0 || (n > 0 && db == nullptr) || image == nullptr) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: bad arguments");
     if (((uintptr_t)image & 15) != 0 || ((uintptr_t)db & 15) != 0) MS_FAIL(MS_ERR_ARG, "ms_pf_build_image: db and image must be 16-byte aligned");
-    if (n == 0) return MS_OK;
-    return ms_launch_pf_build_image(db, n, image, (hipStream_t)stream);
+    if (pf_format == MS_PF_BF16X3) {
+        if (n == 0) return MS_OK;
+        return ms_launch_pf_build_image(db, n, image, (hipStream_t)stream);
+    }
+    // fp16: every component of row * 2^sr must sit below 2^15 -- sr from the bound on the rows' norms
+    if (!(row_norm_bound >= 9.094947e-13f && row_norm_bound <= 1.0995116e12f))
+        MS_FAIL(MS_ERR_RANGE, "ms_pf_build_image: the fp16 image needs a row-norm bound in [2^-40, 2^40] (got %g): use MS_PF_BF16X3", (double)row_norm_bound);
+    const int sr = 14 - ilogbf(row_norm_bound);
+    return ms_launch_pf16_build_image(db, n, sr, image, (hipStream_t)stream);
 }
 
 size_t ms_ip_topk_prefiltered_workspace_bytes(int64_t n, int nq, int k) {
     if (n < 0 || nq < 1 || k < 1) return 0;
     size_t m = make_plan(n, nq, k, cu_count_cached()).total;
-    for (int image = 0; image < 2; ++image) {
-        const size_t a = pf_layout(n, nq, k, image ? MS_MODE_COSINE_UNIT : MS_MODE_IP_PRENORM, image != 0).total;
+    for (int image = 0; image < 3; ++image) {       // no image, split-bf16 image (32-row tiles), fp16 image (64-row tiles)
+        const size_t a = pf_layout(n, nq, k, image ? MS_MODE_COSINE_UNIT : MS_MODE_IP_PRENORM, image != 0, image == 2 ? MS_PF_F16X2 : MS_PF_BF16X3).total;
         if (a > m) m = a;
     }
     return m;
 }
 
-int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered(const float *db, const void *pf_image, int pf_format, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
                            const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores,
                            int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
     if (k > 64) return ms_ip_topk(db, n, row_offset, q, nq, k, mode, nullptr, lengths, qlen, mincov, out_scores, out_idx, workspace, workspace_bytes, stream);
-    return pf_run(7, db, pf_image, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
+    return pf_run(7, db, pf_image, pf_format, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
                   workspace_bytes, (hipStream_t)stream);
 }
-int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered_prepare(const float *db, const void *pf_image, int pf_format, int64_t n, const float *q, int nq, int k, int mode,
                                    const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                    size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(1, db, pf_image, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
+    return pf_run(1, db, pf_image, pf_format, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
                   (hipStream_t)stream);
 }
-int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int64_t n, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered_scan(const float *db, const void *pf_image, int pf_format, int64_t n, const float *q, int nq, int k, int mode,
                                 const float *lengths, const float *qlen, float mincov, float row_norm_bound, void *workspace,
                                 size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(2, db, pf_image, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
+    return pf_run(2, db, pf_image, pf_format, n, 0, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, nullptr, nullptr, workspace, workspace_bytes,
                   (hipStream_t)stream);
 }
-int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
+int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int pf_format, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
                                   const float *lengths, const float *qlen, float mincov, float row_norm_bound, float *out_scores,
                                   int64_t *out_idx, void *workspace, size_t workspace_bytes, ms_stream_t stream) {
-    return pf_run(4, db, pf_image, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
+    return pf_run(4, db, pf_image, pf_format, n, row_offset, q, nq, k, mode, lengths, qlen, mincov, row_norm_bound, out_scores, out_idx, workspace,
                   workspace_bytes, (hipStream_t)stream);
 }
 // Diagnostics for the tests (synchronises the device): the state the last prefiltered search on this workspace left behind --
@@ -1328,7 +1367,8 @@ int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned
 
 // Diagnostics (tools/pf_try.py): the candidate lists (approximate scores, rows) the last prefiltered search left in the workspace.
 int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, int image, float *as_host, int64_t *ai_host, int *kp_out) {
-    const PfLayout L = pf_layout(n, nq, k, MS_MODE_IP_PRENORM, image != 0);
+    // image: 0 = none, 1 = split-bf16 image, 2 = fp16 image (the layouts differ in their tile size only)
+    const PfLayout L = pf_layout(n, nq, k, MS_MODE_IP_PRENORM, image != 0, image == 2 ? MS_PF_F16X2 : MS_PF_BF16X3);
     if (!L.ok || hipDeviceSynchronize() != hipSuccess) return -1;
     *kp_out = L.kp;
     if (hipMemcpy(as_host, (char *)workspace + L.off_as, (size_t)nq * L.kp * 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -97,8 +97,10 @@ def _to_engine(target_dict: dict, engine) -> None:
     target_dict["row_lo"], target_dict["row_hi"] = lo, hi
     target_dict["database"] = engine.cosine_rows(engine.to_device(target_dict["database"][lo:hi].float().contiguous()))
     target_dict["lengths"] = engine.to_device(target_dict["lengths"][lo:hi])
-    # (large query batches: the prefiltered search over the split image of the normalised rows, built once here)
-    target_dict["pf_image"] = engine.pf_image(target_dict["database"]) if hasattr(engine, "pf_image") else None
+    # (large query batches: the prefiltered search over an image of the normalised rows -- built by the first batch of more than 64
+    #  queries, never by a run with a handful of query domains)
+    target_dict["pf_image"] = (engine.lazy_pf_image(target_dict["database"], engine.UNIT_ROW_BOUND)
+                               if hasattr(engine, "lazy_pf_image") else None)
     target_dict["_engine"] = engine
 
 
@@ -417,7 +419,7 @@ def _resident_shard(target_dict: dict, engine, dbmm, lo: int, hi: int, nq: int, 
     cache.update(engine=engine, span=(lo, hi), shard=engine.upload_rows(dbmm, lo, hi))
     if hasattr(engine, "row_norm_bound"):           # (the CPU oracle engine of the tests has no prefiltered search)
         cache["row_norm_bound"] = engine.row_norm_bound(cache["shard"])
-        cache["pf_image"] = engine.pf_image(cache["shard"])
+        cache["pf_image"] = engine.lazy_pf_image(cache["shard"], cache["row_norm_bound"])
     return cache["shard"]
 
 

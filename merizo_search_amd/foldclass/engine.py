@@ -48,6 +48,23 @@ def resolve_device(device) -> str:
     sys.exit(1)
 
 
+class LazyPfImage:
+    """The prefilter's image of a resident matrix, built on first use (HipEngine.lazy_pf_image)."""
+
+    def __init__(self, engine, db, row_norm_bound=None):
+        self._engine, self._db, self._bound, self._image, self._built = engine, db, row_norm_bound, None, False
+
+    @property
+    def built(self) -> bool:
+        return self._built
+
+    def get(self):
+        if not self._built:
+            self._image = self._engine.pf_image(self._db, self._bound)
+            self._built = True
+        return self._image
+
+
 class HipEngine:
     name = "hip"
 
@@ -114,8 +131,10 @@ class HipEngine:
         database became resident): batches of more than 64 queries take the prefiltered search, same results bit for bit."""
         ops = self._ops
         if pf_image is not None and ops.prefilter_serves(rows.shape[0], q.shape[0], k):
-            return ops.ip_topk_prefiltered(rows, q, k, self.UNIT_ROW_BOUND, mode=ops.MODE_COSINE_UNIT, row_offset=row_offset,
-                                           workspace=self._pws, image=pf_image, lengths=lengths, qlen=qlen, mincov=mincov)
+            image = pf_image.get() if isinstance(pf_image, LazyPfImage) else pf_image
+            if image is not None:
+                return ops.ip_topk_prefiltered(rows, q, k, self.UNIT_ROW_BOUND, mode=ops.MODE_COSINE_UNIT, row_offset=row_offset,
+                                               workspace=self._pws, image=image, lengths=lengths, qlen=qlen, mincov=mincov)
         return ops.ip_topk(rows, q, k, mode=ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
                            row_offset=row_offset, workspace=self._ws)
 
@@ -128,24 +147,36 @@ class HipEngine:
         ops = self._ops
         mode = ops.MODE_IP_NORMQ if normalize_queries else ops.MODE_IP_PRENORM
         if row_norm_bound is not None and ops.prefilter_serves(db.shape[0], q.shape[0], k):
+            image = pf_image.get() if isinstance(pf_image, LazyPfImage) else pf_image
             return ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws,
-                                           image=pf_image)
+                                           image=image)
         return ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
 
-    def pf_image(self, db, reserve: int = 6 << 30):
-        """The split-bf16 image of a resident matrix (ops.pf_build_image: +512 B per row; the fp32 rows stay for the exact
-        re-scoring), or None when HBM has no room for it next to `reserve` bytes of workspace -- the prefiltered search then splits
-        the rows in registers (inner-product modes) or the fp32 scan runs (cosine)."""
+    def pf_image(self, db, row_norm_bound=None, reserve: int = 6 << 30):
+        """The prefilter's image of a resident matrix (ops.pf_build_image; the fp32 rows stay for the exact re-scoring): fp16 rows,
+        +256 B per row (MS_PF_F16X2, the default; MS_PF_FORMAT overrides) -- or the split-bf16 image, +512 B per row, when the rows'
+        norm bound leaves the range the fp16 image covers -- or None when HBM has no room for it next to `reserve` bytes of
+        workspace: the prefiltered search then splits the rows in registers (inner-product modes) or the fp32 scan runs (cosine)."""
         from .. import _lib
+        ops = self._ops
         n = int(db.shape[0])
         if n < _lib.PREFILTER_MIN_ROWS or os.environ.get("MERIZO_PF_IMAGE", "1") == "0":
             return None
-        need = int(_lib.load().ms_pf_image_bytes(n))
+        bound = float(row_norm_bound) if row_norm_bound is not None else self.row_norm_bound(db)
+        fmt = ops.pf_default_format()
+        if fmt != ops.PF_BF16X3 and not (2.0 ** -40 <= bound <= 2.0 ** 40):
+            fmt = ops.PF_BF16X3
+        need = int(_lib.load().ms_pf_image_bytes(n, fmt))
         free, _total = self.torch.cuda.mem_get_info(self.device)
         if need + reserve > free:
-            logger.info("no room for the prefilter's split image (%d MiB, %d MiB free): splitting rows in registers" % (need >> 20, free >> 20))
+            logger.info("no room for the prefilter's image (%d MiB, %d MiB free): splitting rows in registers" % (need >> 20, free >> 20))
             return None
-        return self._ops.pf_build_image(db)
+        return ops.pf_build_image(db, fmt=fmt, row_norm_bound=bound)
+
+    def lazy_pf_image(self, db, row_norm_bound=None):
+        """pf_image(db), built by the FIRST batch the prefiltered search serves (more than 64 queries): a CLI run with a handful of
+        query domains never pays the extra pass over the rows nor the image's memory."""
+        return LazyPfImage(self, db, row_norm_bound)
 
     def row_norm_bound(self, db) -> float:
         """max |row| over a resident database, a hair up (one HBM pass; the prefiltered search's error bound scales with it)."""

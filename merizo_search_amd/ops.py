@@ -7,6 +7,8 @@ from __future__ import annotations
 
 from typing import Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -164,19 +166,60 @@ class PrefilterWorkspace(TopKWorkspace):
         return self.buf
 
 
-def pf_build_image(db, out=None):
-    """The split-bf16 image of a resident database for the prefiltered search (ms_pf_build_image): 512 B per row next to the fp32
-    rows, built once.  -> uint8 tensor of ms_pf_image_bytes(n)."""
+PF_BF16X3, PF_F16X2, PF_F16X1 = _lib.PF_BF16X3, _lib.PF_F16X2, _lib.PF_F16X1
+_PF_NAMES = {"bf16x3": PF_BF16X3, "f16x2": PF_F16X2, "f16x1": PF_F16X1}
+
+
+def pf_default_format() -> int:
+    """The prefilter arithmetic the driver uses: fp16 rows x split fp16 queries (MS_PF_F16X2: 256 B per row, 2 matrix instructions per
+    16 dimensions); MS_PF_FORMAT=bf16x3|f16x2|f16x1 overrides (A/B runs, and MS_PF_BF16X3 for databases whose rows leave the fp16 range)."""
+    name = os.environ.get("MS_PF_FORMAT", "f16x2").lower()
+    if name not in _PF_NAMES:
+        raise MerizoHipError(f"MS_PF_FORMAT={name}: expected one of {sorted(_PF_NAMES)}")
+    return _PF_NAMES[name]
+
+
+class PfImage:
+    """An MFMA-ready image of a resident database (ms_pf_build_image) with the arithmetic it was built for.  `data`: uint8 tensor;
+    `format`: PF_BF16X3 (512 B per row) or PF_F16X2 / PF_F16X1 (ONE fp16 image, 256 B per row: `as_format` switches between the two)."""
+    __slots__ = ("data", "format", "n")
+
+    def __init__(self, data, fmt: int, n: int):
+        self.data, self.format, self.n = data, int(fmt), int(n)
+
+    def numel(self) -> int:
+        return self.data.numel()
+
+    def as_format(self, fmt: int) -> "PfImage":
+        if fmt == self.format:
+            return self
+        if PF_BF16X3 in (fmt, self.format):
+            raise MerizoHipError("the split-bf16 image and the fp16 image are different buffers: build the one you want")
+        return PfImage(self.data, fmt, self.n)
+
+
+def pf_err_coef(fmt: int) -> float:
+    """E of the format: |approximate - exact| <= E |row| |q| (ms_pf_err_coef)."""
+    return float(_lib.load().ms_pf_err_coef(int(fmt)))
+
+
+def pf_build_image(db, fmt=None, row_norm_bound=None, out=None) -> PfImage:
+    """The image of a resident database for the prefiltered search (ms_pf_build_image), built once next to the fp32 rows:
+    fp16 rows (PF_F16X2 / PF_F16X1, 256 B per row; needs the rows' norm bound -- measured here when not given) or split-bf16
+    (PF_BF16X3, 512 B per row)."""
     torch = _lib.require_gpu()
     _f32_cuda(db, "db", DIM)
+    fmt = pf_default_format() if fmt is None else int(fmt)
     n = db.shape[0]
-    need = int(_lib.load().ms_pf_image_bytes(n))
+    need = int(_lib.load().ms_pf_image_bytes(n, fmt))
+    if fmt != PF_BF16X3 and row_norm_bound is None:
+        row_norm_bound = (float(1.0 / row_inv_norms(db, 1e-30).min()) * (1.0 + 1e-6)) if n > 0 else 1.0
     img = torch.empty(max(need, 16), dtype=torch.uint8, device=db.device) if out is None else out
     if img.dtype != torch.uint8 or img.numel() < need or not img.is_contiguous():
-        raise MerizoHipError("pf_build_image: out must be a contiguous uint8 tensor of ms_pf_image_bytes(n)")
+        raise MerizoHipError("pf_build_image: out must be a contiguous uint8 tensor of ms_pf_image_bytes(n, fmt)")
     with _on(db, img) as dev:
-        check(_lib.load().ms_pf_build_image(ptr(db), n, ptr(img), dev.stream), "ms_pf_build_image")
-    return img
+        check(_lib.load().ms_pf_build_image(ptr(db), n, fmt, float(row_norm_bound or 0.0), ptr(img), dev.stream), "ms_pf_build_image")
+    return PfImage(img, fmt, n)
 
 
 def small_batch_thresholds():
@@ -200,7 +243,8 @@ def _pf_args(db, image, q, mode, lengths, qlen):
         raise MerizoHipError("ip_topk_prefiltered: MODE_IP_PRENORM, MODE_IP_NORMQ or MODE_COSINE_UNIT")
     if mode != MODE_COSINE_UNIT and (lengths is not None or qlen is not None):
         raise MerizoHipError("ip_topk_prefiltered: lengths / qlen go with MODE_COSINE_UNIT")
-    if image is not None and (image.dtype.itemsize != 1 or image.numel() < int(_lib.load().ms_pf_image_bytes(db.shape[0]))):
+    if image is not None and (not isinstance(image, PfImage) or image.n != db.shape[0] or
+                              image.data.numel() < int(_lib.load().ms_pf_image_bytes(db.shape[0], image.format))):
         raise MerizoHipError("ip_topk_prefiltered: image is not pf_build_image(db)")
     for name, t, size in (("lengths", lengths, db.shape[0]), ("qlen", qlen, q.shape[0])):
         if t is not None:
@@ -211,8 +255,8 @@ def _pf_args(db, image, q, mode, lengths, qlen):
 
 def ip_topk_prefiltered(db, q, k: int, row_norm_bound: float = 1.0, mode: int = MODE_IP_PRENORM, row_offset: int = 0,
                         workspace=None, out=None, image=None, lengths=None, qlen=None, mincov: float = 0.0):
-    """ip_topk with the same results bit for bit, several times faster for more than 64 queries and k <= 48: split-bf16 prefilter
-    scan (over `image` = pf_build_image(db) when given, else splitting the rows in registers), exact re-scoring, per-query proof,
+    """ip_topk with the same results bit for bit, several times faster for more than 64 queries and k <= 48: 16-bit prefilter
+    scan (over `image` = pf_build_image(db) -- fp16 or split-bf16 -- when given, else splitting the rows in registers), exact re-scoring, per-query proof,
     and an exact fp32 pass over the queries whose proof failed (include/merizo_search_amd.h).  row_norm_bound: an upper bound on
     every row's L2 norm (1.0 + 1e-6 for unit rows).  workspace: a PrefilterWorkspace or a uint8 tensor of
     ms_ip_topk_prefiltered_workspace_bytes."""
@@ -225,8 +269,9 @@ def ip_topk_prefiltered(db, q, k: int, row_norm_bound: float = 1.0, mode: int = 
         out_i = torch.empty((nq, k), dtype=torch.int64, device=db.device)
     else:
         out_s, out_i = out
-    with _on(db, q, ws, out_s, out_i, image, lengths, qlen) as dev:
-        check(_lib.load().ms_ip_topk_prefiltered(ptr(db), ptr(image), n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+    idata, ifmt = (image.data, image.format) if image is not None else (None, 0)
+    with _on(db, q, ws, out_s, out_i, idata, lengths, qlen) as dev:
+        check(_lib.load().ms_ip_topk_prefiltered(ptr(db), ptr(idata), ifmt, n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
                                                  float(row_norm_bound), ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream),
               "ms_ip_topk_prefiltered")
     return out_s, out_i
@@ -237,16 +282,17 @@ def ip_topk_prefiltered_stage(stage: str, db, q, k: int, ws, row_norm_bound: flo
     """One stage of ip_topk_prefiltered ('prepare', 'scan', 'finish'): lets a bench time the scan launch alone."""
     lib = _lib.load()
     n, nq = db.shape[0], q.shape[0]
-    with _on(db, q, ws, image, lengths, qlen) as dev:
+    idata, ifmt = (image.data, image.format) if image is not None else (None, 0)
+    with _on(db, q, ws, idata, lengths, qlen) as dev:
         if stage == "prepare":
-            check(lib.ms_ip_topk_prefiltered_prepare(ptr(db), ptr(image), n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+            check(lib.ms_ip_topk_prefiltered_prepare(ptr(db), ptr(idata), ifmt, n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
                                                      float(row_norm_bound), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered_prepare")
         elif stage == "scan":
-            check(lib.ms_ip_topk_prefiltered_scan(ptr(db), ptr(image), n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+            check(lib.ms_ip_topk_prefiltered_scan(ptr(db), ptr(idata), ifmt, n, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
                                                   float(row_norm_bound), ptr(ws), ws.numel(), dev.stream), "ms_ip_topk_prefiltered_scan")
         else:
             out_s, out_i = out
-            check(lib.ms_ip_topk_prefiltered_finish(ptr(db), ptr(image), n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
+            check(lib.ms_ip_topk_prefiltered_finish(ptr(db), ptr(idata), ifmt, n, row_offset, ptr(q), nq, k, mode, ptr(lengths), ptr(qlen), mincov,
                                                     float(row_norm_bound), ptr(out_s), ptr(out_i), ptr(ws), ws.numel(), dev.stream),
                   "ms_ip_topk_prefiltered_finish")
 

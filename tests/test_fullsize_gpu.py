@@ -146,11 +146,16 @@ def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
     # and without an image (rows split in registers) -- indices and score bits of all 4096 lists == the fp32 scan's
     del parts, ms, mi
     ws = ops.PrefilterWorkspace(dev).get(n, nq, k)
-    img = ops.pf_build_image(db)
-    for image in (img, None):
+    img = ops.pf_build_image(db, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6)        # fp16 image: +11.7 GB; F16X1 runs over the same image
+    assert img.numel() == 256 * n + 256
+    for image in (img, img.as_format(ops.PF_F16X1), None):
         sp, ip_ = ops.ip_topk_prefiltered(db, q, k, 1.0 + 1e-6, row_offset=lo, workspace=ws, image=image)
         assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32))
         assert ops.prefilter_flagged(ws) == 0
+    del img
+    img = ops.pf_build_image(db, fmt=ops.PF_BF16X3)                                   # split-bf16 image: +23.4 GB
+    sp, ip_ = ops.ip_topk_prefiltered(db, q, k, 1.0 + 1e-6, row_offset=lo, workspace=ws, image=img)
+    assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32)) and ops.prefilter_flagged(ws) == 0
 
 def test_c4_at_its_real_row_count_on_one_gpu_unsharded_equals_eight_shards_merged(torch_gpu):
     """C4 at the size BASELINE.json states it: 365,000,000 x 128 fp32 rows (186.9 GB) resident on ONE 288 GB MI355X, 4096 queries,

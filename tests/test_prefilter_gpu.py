@@ -1,7 +1,8 @@
-"""GPU parity of the prefiltered search (ms_ip_topk_prefiltered): the rows are scanned with bf16 matrix instructions on split
-operands -- over the split image built once per database (ms_pf_build_image), or splitting in registers without one -- the
-survivors re-scored with the exact fp32 chain, and every query's answer is proved complete -- or that query gets an exact
-pass of its own.  The bar is the one of ms_ip_topk: indices AND score bits identical to the oracle."""
+"""GPU parity of the prefiltered search (ms_ip_topk_prefiltered): the rows are scanned with 16-bit matrix instructions -- over an
+image built once per database (ms_pf_build_image: fp16 rows against split or unsplit fp16 queries, MS_PF_F16X2 / MS_PF_F16X1, or
+bf16 hi + lo halves of both, MS_PF_BF16X3), or splitting in registers without one -- the survivors re-scored with the exact fp32
+chain, and every query's answer is proved complete -- or that query gets an exact pass of its own.  The bar is the one of
+ms_ip_topk, for every arithmetic: indices AND score bits identical to the oracle."""
 import numpy as np
 import pytest
 
@@ -25,11 +26,23 @@ def _norm_db(n, seed):
     return syn.normalized_database(n, seed)
 
 
+IMAGES = ["f16x2", "f16x1", "bf16x3", None]           # the three image arithmetics, and no image (rows split in registers)
+FORMATS = ["f16x2", "f16x1", "bf16x3"]
+
+
+def _img(ops, d, image, bound=None):
+    """image: a format name, True (the driver's default format) or None / False (no image)."""
+    if not image:
+        return None
+    fmt = None if image is True else {"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1, "bf16x3": ops.PF_BF16X3}[image]
+    return ops.pf_build_image(d, fmt=fmt, row_norm_bound=bound)
+
+
 def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fallback=None, image=True, expect_flagged=None):
     d, dq = _dev(torch, db), _dev(torch, q)
     ws = ops.PrefilterWorkspace(d.device).get(db.shape[0], q.shape[0], k)
     mode = ops.MODE_IP_NORMQ if raw else ops.MODE_IP_PRENORM
-    img = ops.pf_build_image(d) if image else None
+    img = _img(ops, d, image, bound)
     s, i = ops.ip_topk_prefiltered(d, dq, k, bound, mode=mode, row_offset=row_offset, workspace=ws, image=img)
     flagged = ops.prefilter_flagged(ws)
     fell_back = flagged > 0
@@ -44,7 +57,7 @@ def _check(torch, ops, orc, db, q, k, bound, row_offset=0, raw=False, expect_fal
     return fell_back
 
 
-@pytest.mark.parametrize("image", [True, False])
+@pytest.mark.parametrize("image", IMAGES)
 @pytest.mark.parametrize("n,nq,k", [(70_000, 65, 1), (70_000, 100, 5), (131_105, 97, 10), (300_000, 256, 10), (262_113, 130, 16),
                                     (400_000, 200, 20), (200_000, 129, 32), (300_000, 100, 40), (1_000_003, 256, 10), (100_000, 1000, 3),
                                     (65_536, 160, 10), (99_999, 161, 7), (250_000, 300, 48)])
@@ -57,7 +70,7 @@ def test_prefiltered_is_bit_identical_and_needs_no_exact_pass_on_ordinary_data(n
     _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=11, expect_fallback=False, image=image)
 
 
-@pytest.mark.parametrize("image", [True, False])
+@pytest.mark.parametrize("image", IMAGES)
 def test_prefiltered_raw_queries_and_rows_that_are_not_unit_vectors(image, torch_gpu):
     """MS_MODE_IP_NORMQ (F.normalize inside the call) and a database whose rows have norms 0.2 .. 3: the error bound scales with
     the row-norm bound the caller measured."""
@@ -75,7 +88,7 @@ def test_prefiltered_raw_queries_and_rows_that_are_not_unit_vectors(image, torch
     _check(torch, ops, orc, db, q, k, bound, image=image)
 
 
-@pytest.mark.parametrize("image", [True, False])
+@pytest.mark.parametrize("image", IMAGES)
 def test_prefiltered_near_ties_by_the_hundred_fall_back_to_the_exact_pipeline(image, torch_gpu):
     """300 rows within 1e-6 of each other around every query's best score (copies of the query's own direction with tiny
     perturbations) and blocks of exact duplicates: no proof can succeed, every query gets the exact pass."""
@@ -99,8 +112,9 @@ def _family(rng, qvec, count, sigma=2e-7):
     return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
 
 
+@pytest.mark.parametrize("image", FORMATS)
 @pytest.mark.parametrize("which", ["one", "seventeen", "all", "tile_edges", "last_only"])
-def test_queries_whose_proof_fails_get_an_exact_pass_of_their_own(which, torch_gpu):
+def test_queries_whose_proof_fails_get_an_exact_pass_of_their_own(which, image, torch_gpu):
     """Per-query exact fallback (the reference's semantics are per query: dbsearch.py:234-242): only the queries that own a family
     of 200 near-duplicates fail their proof; they are compacted on the device, scanned exactly and scattered back; every other
     query keeps the prefilter's (proved) answer.  All 256 answers == the oracle's, and the flagged count is exactly the planted one."""
@@ -115,7 +129,7 @@ def test_queries_whose_proof_fails_get_an_exact_pass_of_their_own(which, torch_g
     rows = rng.choice(n, size=(len(owners), 200), replace=False)
     for j, qi in enumerate(owners):
         db[rows[j]] = _family(rng, q[qi], 200)
-    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=3, expect_flagged=len(owners))
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=3, expect_flagged=len(owners), image=image)
 
 
 def test_flagged_queries_in_a_large_batch_and_long_lists(torch_gpu):
@@ -145,7 +159,8 @@ def _cosine_case(n, nq, seed, masked_fraction=0.5):
 
 @pytest.mark.parametrize("n,nq,k,mincov", [(200_000, 256, 10, 0.7), (131_071, 100, 5, 0.0), (300_000, 1000, 10, 0.7), (100_000, 130, 20, 1.5),
                                            (70_000, 97, 1, 0.7)])
-def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, torch_gpu):
+@pytest.mark.parametrize("image", FORMATS)
+def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, image, torch_gpu):
     """MS_MODE_COSINE_UNIT through the prefilter (search_query_against_db on rows normalised once, dbsearch.py:75-81): the length
     mask multiplies the approximate and the exact score by the same 0 / 1, so the proof holds; results == ms_ip_topk's bit for bit
     and == the oracle's cosine_topk (near-tie aware)."""
@@ -156,7 +171,7 @@ def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, 
     db, q, lengths, qlen = _cosine_case(n, nq, seed=500 + k)
     d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
     unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
-    img = ops.pf_build_image(unit)
+    img = _img(ops, unit, image, 1.0 + 1e-5)
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
     kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=mincov)
     s0, i0 = ops.ip_topk(unit, dq, k, row_offset=7, **kw)
@@ -169,7 +184,8 @@ def test_prefiltered_cosine_on_unit_rows_equals_the_fp32_scan(n, nq, k, mincov, 
     assert_topk_equivalent(s1.cpu().numpy()[sel], i1.cpu().numpy()[sel], s_ref, i_ref, tol=2e-6)
 
 
-def test_prefiltered_cosine_with_every_row_masked_and_with_families(torch_gpu):
+@pytest.mark.parametrize("image", FORMATS)
+def test_prefiltered_cosine_with_every_row_masked_and_with_families(image, torch_gpu):
     """Everything masked for some queries (all scores +-0: ties by the thousand, resolved by row; those queries fail their proof and
     get the exact pass) and near-duplicate families for others."""
     torch = torch_gpu
@@ -185,7 +201,7 @@ def test_prefiltered_cosine_with_every_row_masked_and_with_families(torch_gpu):
         qlen[50 + j] = 300.0
     d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
     unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
-    img = ops.pf_build_image(unit)
+    img = _img(ops, unit, image, 1.0 + 1e-5)
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
     kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=0.7)
     s0, i0 = ops.ip_topk(unit, dq, k, **kw)
@@ -203,7 +219,7 @@ def test_prefiltered_shapes_it_does_not_serve_take_the_plain_path(n, nq, k, torc
     _check(torch, ops, orc, _norm_db(n, seed=431), _norm_db(nq, seed=432), k, 1.0 + 1e-6)
 
 
-@pytest.mark.parametrize("image", [True, False])
+@pytest.mark.parametrize("image", IMAGES)
 def test_prefiltered_stages_equal_the_one_shot_call_and_repeat(image, torch_gpu):
     torch = torch_gpu
     from merizo_search_amd import ops
@@ -211,7 +227,7 @@ def test_prefiltered_stages_equal_the_one_shot_call_and_repeat(image, torch_gpu)
     db, q = _norm_db(n, seed=441), _norm_db(nq, seed=442)
     d, dq = _dev(torch, db), _dev(torch, q)
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
-    img = ops.pf_build_image(d) if image else None
+    img = _img(ops, d, image)
     s0, i0 = ops.ip_topk(d, dq, k)
     out = (torch.empty_like(s0), torch.empty_like(i0))
     for _ in range(3):
@@ -230,6 +246,7 @@ def test_prefiltered_stages_equal_the_one_shot_call_and_repeat(image, torch_gpu)
 def test_engine_uses_the_prefilter_for_large_batches_on_a_resident_database(torch_gpu):
     """foldclass/engine.py: ip_topk with a row-norm bound (what dbsearch_faiss passes for a resident shard) == without."""
     torch = torch_gpu
+    from merizo_search_amd import ops
     from merizo_search_amd.foldclass import engine as eng
     e = eng.HipEngine("cuda:0")
     db, q = _norm_db(300_000, seed=451), _norm_db(200, seed=452)
@@ -237,7 +254,13 @@ def test_engine_uses_the_prefilter_for_large_batches_on_a_resident_database(torc
     bound = e.row_norm_bound(d)
     assert 1.0 <= bound < 1.0001
     img = e.pf_image(d)
-    assert img is not None and img.numel() >= 512 * d.shape[0]
+    assert img is not None and img.format == ops.PF_F16X2 and 256 * d.shape[0] <= img.numel() <= 256 * (d.shape[0] + 64) + 256
+    lazy = e.lazy_pf_image(d, bound)
+    assert not lazy.built
+    s1, i1 = e.ip_topk(d, dq[:40], 10, row_offset=5, normalize_queries=True, row_norm_bound=bound, pf_image=lazy)     # 40 queries: no image built
+    assert not lazy.built
+    s1, i1 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True, row_norm_bound=bound, pf_image=lazy)
+    assert lazy.built and lazy.get() is not None
     s0, i0 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True)
     for image in (img, None):
         s1, i1 = e.ip_topk(d, dq, 10, row_offset=5, normalize_queries=True, row_norm_bound=bound, pf_image=image)
@@ -302,7 +325,7 @@ def test_engine_keeps_the_prefilter_on_clustered_data_batch_after_batch(torch_gp
         assert len(owners) <= ops.prefilter_flagged(e._pws.buf) <= len(owners) + 4
 
 
-@pytest.mark.parametrize("image", [True, False])
+@pytest.mark.parametrize("image", IMAGES)
 @pytest.mark.parametrize("k", [10, 40])
 def test_prefiltered_repeated_searches_return_identical_results(k, image, torch_gpu):
     """Run-to-run determinism of the prefiltered search (100 runs of one search; the first against the fp32 scan)."""
@@ -311,9 +334,76 @@ def test_prefiltered_repeated_searches_return_identical_results(k, image, torch_
     n, nq = 202_000, 738
     d, dq = _dev(torch, _norm_db(n, seed=46)), _dev(torch, _norm_db(nq, seed=47))
     ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
-    img = ops.pf_build_image(d) if image else None
+    img = _img(ops, d, image)
     s_ref, i_ref = ops.ip_topk(d, dq, k)
     for _ in range(100):
         s, i = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, workspace=ws, image=img)
         assert torch.equal(i, i_ref) and torch.equal(s.view(torch.int32), s_ref.view(torch.int32))
     assert not ops.prefilter_fell_back(ws)
+
+
+def test_fp16_image_builder_declines_row_norms_outside_its_range_and_the_engine_falls_back_to_split_bf16(torch_gpu):
+    """The fp16 image stores row * 2^sr: a row-norm bound outside [2^-40, 2^40] is refused (MS_ERR_RANGE); the engine then builds
+    the split-bf16 image, whose arithmetic has the range of fp32.  Tiny rows (norm 1e-14) searched through it: exact."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd._lib import MerizoHipError
+    from merizo_search_amd.foldclass import engine as eng
+    from oracle import oracle as orc
+    n, nq, k = 100_000, 100, 10
+    db = (_norm_db(n, seed=531) * np.float32(1e-14)).astype(np.float32)
+    q = _norm_db(nq, seed=532)
+    d, dq = _dev(torch, db), _dev(torch, q)
+    with pytest.raises(MerizoHipError, match="row-norm bound"):
+        ops.pf_build_image(d, fmt=ops.PF_F16X2, row_norm_bound=1e-14)
+    e = eng.HipEngine("cuda:0")
+    bound = e.row_norm_bound(d)
+    img = e.pf_image(d, bound)
+    assert img is not None and img.format == ops.PF_BF16X3
+    s, i = e.ip_topk(d, dq, k, row_norm_bound=bound, pf_image=img)
+    s_ref, i_ref = orc.ip_topk(db, q, k, order=1)
+    assert np.array_equal(i.cpu().numpy(), i_ref) and np.array_equal(s.cpu().numpy().view(np.uint32), s_ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("scale", [2.0 ** -30, 3.0e4, 7.5e8])
+@pytest.mark.parametrize("image", ["f16x2", "f16x1"])
+def test_fp16_image_scales_rows_and_queries_of_any_magnitude_into_range(image, scale, torch_gpu):
+    """Rows of norm ~scale (and queries 1000x smaller / larger than that) go through the fp16 image: the image stores row * 2^sr, every
+    query is scaled by its own power of two, the proof's bound scales with the row-norm bound.  Exact; nothing flagged."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, nq, k = 150_000, 130, 10
+    db = (_norm_db(n, seed=541) * np.float32(scale)).astype(np.float32)
+    q = _norm_db(nq, seed=542)
+    q[: nq // 2] *= np.float32(1e-3 / scale)
+    q[nq // 2:] *= np.float32(1e3 * scale)
+    bound = float(np.linalg.norm(db.astype(np.float64), axis=1).max()) * (1 + 1e-6)
+    _check(torch, ops, orc, db, q.astype(np.float32), k, bound, expect_fallback=False, image=image)
+
+
+def test_fp16_image_of_the_wrong_database_traps_instead_of_answering(torch_gpu, tmp_path):
+    """The fp16 image carries a trailer (magic, scale exponent, rows) the scan checks: a split-bf16 image passed as MS_PF_F16X2 makes
+    the launch trap -- in a child process, because a trap poisons the HIP context."""
+    import subprocess
+    import sys
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+d = syn.device_database(100000, 0, seed=0, device="cuda:0"); q = syn.device_database(100, 0, seed=1, device="cuda:0")
+img = ops.pf_build_image(d, fmt=ops.PF_BF16X3)
+bad = ops.PfImage(img.data, ops.PF_F16X2, img.n)         # (a 512 B/row buffer: large enough, wrong content)
+try:
+    s, i = ops.ip_topk_prefiltered(d, q, 10, 1.0 + 1e-6, image=bad)
+    torch.cuda.synchronize()
+    print("ANSWERED")
+except Exception as exc:
+    print("FAILED LOUDLY", type(exc).__name__)
+""" % repo
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "ANSWERED" not in r.stdout, r.stdout + r.stderr[-2000:]
+    assert "FAILED LOUDLY" in r.stdout or r.returncode != 0

@@ -132,7 +132,8 @@ if rank == 0:
     time.sleep(9.0)                              # rank 0 alone reports
     open(sys.argv[2], "w").write("written by rank 0\n")
 sharded.finalize_distributed()
-print("rank", rank, "finalized")
+sys.stdout.write("rank %d finalized\n" % rank)          # (ONE write: two ranks share the pipe)
+sys.stdout.flush()
 """)
     env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", MERIZO_DIST_TIMEOUT_S="5", OMP_NUM_THREADS="1")
     out = tmp_path / "report.txt"

@@ -211,7 +211,9 @@ class SearchBench:
         self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_total // self.world, self.nq, self.k)
         if self.prefilter and self.image is None:
             self.row_norm_bound = float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)
-            self.image = ops.pf_build_image(self.db, row_norm_bound=self.row_norm_bound)     # (the driver's default format: MS_PF_F16X2)
+            self.image = ops.pf_build_image(self.db, row_norm_bound=self.row_norm_bound)     # (as the driver does: the fp16 image, then
+            if ops.pf_format_is_auto():                                                       #  F16X1 or F16X2 by searching 256 of its rows)
+                self.image = ops.pf_choose_format(self.db, self.image, self.row_norm_bound)
             fmt_env = os.environ.get("MS_BENCH_PF_FORMAT")                                    # A/B runs: f16x1 over the same image
             if fmt_env:
                 self.image = self.image.as_format({"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1, "bf16x3": ops.PF_BF16X3}[fmt_env])
@@ -435,7 +437,9 @@ def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
     log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
     state = {"unit": unit, "lengths": lengths, "mincov": mincov, "n": n, "k": k, "image": None, "pws": None}
     if prefilter and ops.prefilter_serves(n, nq, k):
-        img = ops.pf_build_image(unit)
+        img = ops.pf_build_image(unit, row_norm_bound=1.0 + 1e-5)
+        if ops.pf_format_is_auto():
+            img = ops.pf_choose_format(unit, img, 1.0 + 1e-5)
         pws = torch.empty_like(ops.PrefilterWorkspace(dev).get(n, nq, k))
         ps, pi = torch.empty_like(out_s), torch.empty_like(out_i)
         pkw = dict(row_norm_bound=1.0 + 1e-5, image=img, **kw)

@@ -559,12 +559,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
         const float other = ms_xor32_f(smax, h);
         if (h == 0) {
             const float hi = (other > smax) ? other : smax, lo = (other > smax) ? smax : other;
-            const size_t o = ((size_t)qidx * p.k + 0) * p.P + stream;
+            const size_t o = ((size_t)stream * p.nq_pad + qidx) * p.k;          // stream-major lists (below)
             p.part_s[o] = hi;
             p.part_i[o] = (hi > -INFINITY) ? (uint32_t)(2 * stream) : MS_IDX_NONE;
             if (p.k > 1) {
-                p.part_s[o + p.P] = lo;
-                p.part_i[o + p.P] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
+                p.part_s[o + 1] = lo;
+                p.part_i[o + 1] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
             }
         }
         return;
@@ -573,7 +573,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     for (int j = 0; j < (SAMPLE ? 1 : KL); ++j) {
         const int rank = h * KL + j;
         if (rank < p.k) {
-            const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+            // STREAM-MAJOR lists, [stream][query][rank] (round 5): a workgroup's lists are ONE contiguous block (a wave's 32 queries:
+            // 32 k entries back to back), which the L2 merges into whole lines before they leave for HBM.  The rank-major layout of
+            // the fp32 scans ([query][rank][stream]) put every 4-byte entry of this kernel on a line of its own, shared with 255
+            // other workgroups on other XCDs: 118 MB of HBM writes for a 10 MB payload at C2, ~25 us of the launch
+            // (profiles/r05_pf_list_layout_ab.log).  ms_sample_bound_kernel and ms_block_merge_kernel read it (`sm_stride`).
+            const size_t o = ((size_t)stream * p.nq_pad + qidx) * p.k + rank;
             p.part_s[o] = st.ls[j];
             p.part_i[o] = st.li[j];
         }

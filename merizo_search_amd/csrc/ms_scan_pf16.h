@@ -378,15 +378,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             MS_PF16_MAX(mx, pv0);
             MS_PF16_MAX(mx1, pv1);
 #undef MS_PF16_MAX
-            mx = fmaxf(mx, mx1);
+            // (each half tile is visited only if one of ITS scores passes: a visit costs ~900 cycles per half, candidate or not)
+            const bool hit0 = __ballot(mx > tau_s) != 0, hit1 = __ballot(mx1 > tau_s) != 0;
 #ifdef MS_PF2_NOVISIT
             asm volatile("" ::"v"(mx));
             if (false) {
 #else
-            if (__builtin_expect(__ballot(mx > tau_s) != 0 || neg_tau, 0)) {
+            if (__builtin_expect(hit0 || hit1 || neg_tau, 0)) {
 #endif
                 PF2_T0();
-                if (t > 0) { visit(pv0, t - 1, 0, false); visit(pv1, t - 1, 1, false); }
+                if (t > 0) {
+                    if (hit0 || neg_tau) visit(pv0, t - 1, 0, false);
+                    if (hit1 || neg_tau) visit(pv1, t - 1, 1, false);
+                }
                 if (mask_on) neg_tau = __ballot(st.tau < 0.0f) != 0;
 #ifdef MS_STAMP
                 sp_nvis += 1;
@@ -580,21 +584,29 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         const float other = ms_xor32_f(smax, h);
         if (h == 0) {
             const float hi = (other > smax) ? other : smax, lo = (other > smax) ? smax : other;
-            const size_t o = ((size_t)qidx * p.k + 0) * p.P + stream;
+            const size_t o = ((size_t)stream * p.nq_pad + qidx) * p.k;          // stream-major lists (below)
             p.part_s[o] = hi;
             p.part_i[o] = (hi > -INFINITY) ? (uint32_t)(2 * stream) : MS_IDX_NONE;
             if (p.k > 1) {
-                p.part_s[o + p.P] = lo;
-                p.part_i[o + p.P] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
+                p.part_s[o + 1] = lo;
+                p.part_i[o + 1] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
             }
         }
         return;
     }
+#ifdef MS_PF16_NOWRITE          // (diagnostic build: what do the list stores cost?)
+    if (p.k > 0) return;
+#endif
 #pragma unroll
     for (int j = 0; j < (SAMPLE ? 1 : KL); ++j) {
         const int rank = h * KL + j;
         if (rank < p.k) {
-            const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+            // STREAM-MAJOR lists, [stream][query][rank] (round 5): a workgroup's lists are ONE contiguous block (a wave's 32 queries:
+            // 32 k entries back to back), which the L2 merges into whole lines before they leave for HBM.  The rank-major layout of
+            // the fp32 scans ([query][rank][stream]) put every 4-byte entry of this kernel on a line of its own, shared with 255
+            // other workgroups on other XCDs: 118 MB of HBM writes for a 10 MB payload at C2, ~25 us of the launch
+            // (profiles/r05_pf_list_layout_ab.log).  ms_sample_bound_kernel and ms_block_merge_kernel read it (`sm_stride`).
+            const size_t o = ((size_t)stream * p.nq_pad + qidx) * p.k + rank;
             p.part_s[o] = st.ls[j];
             p.part_i[o] = st.li[j];
         }

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
-                                                             const ScanDevPlan *dp, const int *qmap, int sparse) {
+                                                             const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
     if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int q = blockIdx.x;
@@ -228,6 +228,8 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
     const int tid = threadIdx.x, kP = k * P;
     uint2 *ent = reinterpret_cast<uint2 *>(smem + MS_BLOCK_MERGE_SCRATCH);
     const size_t base = (size_t)q * kP;
+    // entry (rank r, list l) of this query: rank-major [k][P] per query, or (sm_stride > 0) stream-major [list][query][rank]
+    auto at = [&](int r, int l) -> size_t { return sm_stride != 0 ? (size_t)l * sm_stride + (size_t)q * k + r : base + (size_t)r * P + l; };
     if (sparse) {
         // SPARSE lists (the prefilter's: 256 streams, 20 slots each, ~100 entries in all -- a bound filtered the rest): every thread
         // walks its own list (four ranks in one round trip, further ones only where the fourth is occupied) and appends what it finds
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 i4[r] = MS_IDX_NONE; s4[r] = -INFINITY;
-                if (r < k) { s4[r] = part_s[base + (size_t)r * P + l]; i4[r] = part_i[base + (size_t)r * P + l]; }
+                if (r < k) { s4[r] = part_s[at(r, l)]; i4[r] = part_i[at(r, l)]; }
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -254,10 +256,10 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
             }
             if (k > 4 && i4[3] != MS_IDX_NONE) {
                 for (int r = 4; r < k; ++r) {
-                    const uint32_t ii = part_i[base + (size_t)r * P + l];
+                    const uint32_t ii = part_i[at(r, l)];
                     if (ii == MS_IDX_NONE) break;
                     const int pos = atomicAdd(&pool_n, 1);
-                    if (pos < 512) { const uint2 e = make_uint2(__float_as_uint(part_s[base + (size_t)r * P + l]), ii); pk[pos] = ms_order_key(e); pe[pos] = e; }
+                    if (pos < 512) { const uint2 e = make_uint2(__float_as_uint(part_s[at(r, l)]), ii); pk[pos] = ms_order_key(e); pe[pos] = e; }
                 }
             }
         }
@@ -284,7 +286,10 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
         }
         __syncthreads();            // (the pool is abandoned: the scratch area is the general merge's from here on)
     }
-    if ((kP & 3) == 0) {
+    if (sm_stride != 0) {           // stream-major: thread l copies its list (k contiguous entries) into the [k][P] staging order
+        for (int l = tid; l < P; l += 256)
+            for (int r = 0; r < k; ++r) ent[(size_t)r * P + l] = make_uint2(__float_as_uint(part_s[at(r, l)]), part_i[at(r, l)]);
+    } else if ((kP & 3) == 0) {
         const float4 *ps4 = reinterpret_cast<const float4 *>(part_s + base);
         const uint4 *pi4 = reinterpret_cast<const uint4 *>(part_i + base);
 #pragma unroll 4
@@ -321,8 +326,10 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
 // Values only (no rows, no sorted output): one wave per query, the values in registers, k rounds of "largest value
 // below the previous one + how many lanes hold it".  -inf when there are fewer than k sampled rows.
 template <int VPL>      // values per lane: ranks * P <= 64 * VPL
+// sm_stride > 0: the lists are STREAM-MAJOR ([stream][query][rank], the image scans of the prefilter: ms_scan_pf.h) -- entry (rank r,
+// list l) of query q is at l * sm_stride + q * k + r, sm_stride = nq_pad * k; 0: rank-major per query ([query][rank][stream]).
 __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb, uint32_t *hist,
-                                                            float *hstep, const uint32_t *gate, uint32_t gate_epoch) {
+                                                            float *hstep, const uint32_t *gate, uint32_t gate_epoch, size_t sm_stride) {
     if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     const int q = blockIdx.x, lane = threadIdx.x;
     const float *ps = part_s + (size_t)q * k * P;              // rank-major [k][P]: the first ranks * P floats
@@ -331,7 +338,8 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const int idx = lane + 64 * i;
-        v[i] = idx < count ? ps[idx] : -INFINITY;
+        if (sm_stride == 0) v[i] = idx < count ? ps[idx] : -INFINITY;
+        else v[i] = idx < count ? part_s[(size_t)(idx % P) * sm_stride + (size_t)q * k + idx / P] : -INFINITY;
     }
     float cur = INFINITY, kth = -INFINITY, top = -INFINITY;
     int remaining = k;
@@ -809,7 +817,7 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 // plan (pl.P is then its upper bound), query q of the compacted batch is output row qmap[q]
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st,
-                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0) {
+                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0, size_t sm_stride = 0) {
     const uint32_t *gate = sp.gate;
     const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
@@ -820,11 +828,12 @@ int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0, sm_stride);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
     if (dp != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the exact pass behind the prefilter needs the block merge (P = %d, k = %d)", pl.P, kp);
+    if (sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: stream-major lists need the block merge (P = %d, k = %d)", pl.P, kp);
     if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
@@ -923,11 +932,13 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
         if (ranks > cap) ranks = cap > 1 ? cap : 1;
     }
     const int vpl = (ranks * pl.P + 63) / 64;
+    const size_t sm_stride = (s0.prefilter && s0.pf_image != nullptr) ? (size_t)pl.nq_pad * s0.k : 0;       // (the image scans write stream-major lists)
+    if (vpl > 32 && sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: %d sample lists of the image scan exceed the bound selection", pl.P);
     if (vpl <= 32) {
         const bool hist_on = pl.qwb == 4 && loader_wave_setting() && hist_setting();
         uint32_t *hist = hist_on ? reinterpret_cast<uint32_t *>(ws + pl.off_hist) : nullptr;
         float *hstep = reinterpret_cast<float *>(ws + pl.off_hstep);
-#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb, hist, hstep, s0.gate, s0.gate_epoch)
+#define MS_BOUND(V) hipLaunchKernelGGL(ms_sample_bound_kernel<V>, dim3(nq), dim3(64), 0, st, s0.part_s, pl.P, s0.k, ranks, lb, hist, hstep, s0.gate, s0.gate_epoch, sm_stride)
         if (vpl <= 4) { MS_BOUND(4); }
         else if (vpl <= 8) { MS_BOUND(8); }
         else if (vpl <= 16) { MS_BOUND(16); }
@@ -1183,7 +1194,7 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image, int format = 
         if (d.P > L.exact_P_max) L.exact_P_max = d.P;
         if ((size_t)d.nq_pad * d.P > lists_max) lists_max = (size_t)d.nq_pad * d.P;
     }
-    if (L.exact_P_max > 256) {       // the merge behind the exact pass stages <= 256 lists per query (a device with more than 256 CUs): ms_ip_topk
+    if (L.exact_P_max > 256 || L.pf.P > 256) {       // the merges behind the image scan and the exact pass stage <= 256 lists per query (a device with more than 256 CUs): ms_ip_topk
         L.ok = false;
         L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0;
         return L;
@@ -1253,7 +1264,8 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         if (out_scores == nullptr || out_idx == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: NULL outputs");
         float *as = reinterpret_cast<float *>(ws + L.off_as);
         int64_t *ai = reinterpret_cast<int64_t *>(ws + L.off_ai);
-        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1);     // (sparse lists)
+        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1,
+                          image != nullptr ? (size_t)pl.nq_pad * L.kp : 0);     // (sparse lists; stream-major behind the image scans)
         if (rc) return rc;
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
         const uint32_t epoch = next_epoch();

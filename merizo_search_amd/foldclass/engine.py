@@ -171,7 +171,12 @@ class HipEngine:
         if need + reserve > free:
             logger.info("no room for the prefilter's image (%d MiB, %d MiB free): splitting rows in registers" % (need >> 20, free >> 20))
             return None
-        return ops.pf_build_image(db, fmt=fmt, row_norm_bound=bound)
+        image = ops.pf_build_image(db, fmt=fmt, row_norm_bound=bound)
+        if fmt != ops.PF_BF16X3 and ops.pf_format_is_auto():
+            # one or two matrix instructions per 16 dimensions?  Decided once per database by searching 256 of its own rows
+            image = ops.pf_choose_format(db, image, bound)
+            logger.info("prefilter arithmetic for this database: %s" % ("MS_PF_F16X1" if image.format == ops.PF_F16X1 else "MS_PF_F16X2"))
+        return image
 
     def lazy_pf_image(self, db, row_norm_bound=None):
         """pf_image(db), built by the FIRST batch the prefiltered search serves (more than 64 queries): a CLI run with a handful of

@@ -171,12 +171,19 @@ _PF_NAMES = {"bf16x3": PF_BF16X3, "f16x2": PF_F16X2, "f16x1": PF_F16X1}
 
 
 def pf_default_format() -> int:
-    """The prefilter arithmetic the driver uses: fp16 rows x split fp16 queries (MS_PF_F16X2: 256 B per row, 2 matrix instructions per
-    16 dimensions); MS_PF_FORMAT=bf16x3|f16x2|f16x1 overrides (A/B runs, and MS_PF_BF16X3 for databases whose rows leave the fp16 range)."""
-    name = os.environ.get("MS_PF_FORMAT", "f16x2").lower()
+    """The image the driver builds: fp16 rows (256 B per row; MS_PF_F16X2 / MS_PF_F16X1 share it -- which of the two arithmetics runs
+    is decided per database by pf_choose_format unless MS_PF_FORMAT names one); MS_PF_FORMAT=bf16x3|f16x2|f16x1|auto overrides
+    (A/B runs; MS_PF_BF16X3 is also what the engine falls back to for databases whose rows leave the fp16 range)."""
+    name = os.environ.get("MS_PF_FORMAT", "auto").lower()
+    if name == "auto":
+        return PF_F16X2
     if name not in _PF_NAMES:
-        raise MerizoHipError(f"MS_PF_FORMAT={name}: expected one of {sorted(_PF_NAMES)}")
+        raise MerizoHipError(f"MS_PF_FORMAT={name}: expected one of {sorted(_PF_NAMES) + ['auto']}")
     return _PF_NAMES[name]
+
+
+def pf_format_is_auto() -> bool:
+    return os.environ.get("MS_PF_FORMAT", "auto").lower() == "auto"
 
 
 class PfImage:
@@ -220,6 +227,26 @@ def pf_build_image(db, fmt=None, row_norm_bound=None, out=None) -> PfImage:
     with _on(db, img) as dev:
         check(_lib.load().ms_pf_build_image(ptr(db), n, fmt, float(row_norm_bound or 0.0), ptr(img), dev.stream), "ms_pf_build_image")
     return PfImage(img, fmt, n)
+
+
+def pf_choose_format(db, image: PfImage, row_norm_bound: float, nsample: int = 256, k: int = 10, max_flagged: float = 0.02) -> PfImage:
+    """F16X1 or F16X2 for a resident database, decided ONCE by running the search itself: `nsample` rows of the database, evenly
+    spaced, are searched as queries (top-k) with the one-instruction arithmetic (MS_PF_F16X1: E = 1.05e-3 |row||q|); if more than
+    `max_flagged` of them fail their proof -- the database has families of rows within ~1e-3 of each other around its own entries,
+    as real embedding databases do -- the two-instruction arithmetic (MS_PF_F16X2, E = 5.5e-4) is used from then on (the SAME
+    image: nothing is rebuilt).  The answers are exact either way; this only picks the faster of two exact paths.  One sync."""
+    torch = _lib.require_gpu()
+    if image is None or image.format == PF_BF16X3:
+        return image
+    n = db.shape[0]
+    if not prefilter_serves(n, max(nsample, 65), k):
+        return image
+    idx = torch.linspace(0, n - 1, nsample, device=db.device).long()
+    q = db[idx].contiguous()
+    ws = PrefilterWorkspace(db.device).get(n, nsample, k)
+    ip_topk_prefiltered(db, q, k, row_norm_bound, mode=MODE_IP_NORMQ, workspace=ws, image=image.as_format(PF_F16X1))
+    flagged = prefilter_flagged(ws)
+    return image.as_format(PF_F16X1 if flagged <= max_flagged * nsample else PF_F16X2)
 
 
 def small_batch_thresholds():

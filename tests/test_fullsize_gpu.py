@@ -147,7 +147,7 @@ def test_c4_per_gpu_shard_shape_45_6M_rows_4096_queries(torch_gpu):
     del parts, ms, mi
     ws = ops.PrefilterWorkspace(dev).get(n, nq, k)
     img = ops.pf_build_image(db, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6)        # fp16 image: +11.7 GB; F16X1 runs over the same image
-    assert img.numel() == 256 * n + 256
+    assert img.numel() == (n + 63) // 64 * 16384 + 256                                  # 256 B per row (+ the trailer)
     for image in (img, img.as_format(ops.PF_F16X1), None):
         sp, ip_ = ops.ip_topk_prefiltered(db, q, k, 1.0 + 1e-6, row_offset=lo, workspace=ws, image=image)
         assert torch.equal(ip_, i) and torch.equal(sp.view(torch.int32), s.view(torch.int32))

@@ -254,7 +254,7 @@ def test_engine_uses_the_prefilter_for_large_batches_on_a_resident_database(torc
     bound = e.row_norm_bound(d)
     assert 1.0 <= bound < 1.0001
     img = e.pf_image(d)
-    assert img is not None and img.format == ops.PF_F16X2 and 256 * d.shape[0] <= img.numel() <= 256 * (d.shape[0] + 64) + 256
+    assert img is not None and img.format == ops.PF_F16X1 and 256 * d.shape[0] <= img.numel() <= 256 * (d.shape[0] + 64) + 256
     lazy = e.lazy_pf_image(d, bound)
     assert not lazy.built
     s1, i1 = e.ip_topk(d, dq[:40], 10, row_offset=5, normalize_queries=True, row_norm_bound=bound, pf_image=lazy)     # 40 queries: no image built
@@ -407,3 +407,28 @@ except Exception as exc:
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert "ANSWERED" not in r.stdout, r.stdout + r.stderr[-2000:]
     assert "FAILED LOUDLY" in r.stdout or r.returncode != 0
+
+
+def test_the_arithmetic_is_chosen_per_database_by_searching_its_own_rows(torch_gpu):
+    """ops.pf_choose_format (what engine.pf_image runs once per resident database): i.i.d. rows -> one matrix instruction per 16
+    dimensions (MS_PF_F16X1); a database made of families of rows within ~4e-4 of each other (cosine) -> two (MS_PF_F16X2), over the same
+    image.  Either way the answers are the fp32 scan's."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    n, nq, k = 200_000, 128, 10
+    plain = _dev(torch, _norm_db(n, seed=551))
+    img = ops.pf_build_image(plain, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6)
+    assert ops.pf_choose_format(plain, img, 1.0 + 1e-6).format == ops.PF_F16X1
+    rng = np.random.default_rng(11)
+    centres = _norm_db(4000, seed=552)
+    fam = centres[rng.integers(0, 4000, size=n)] + rng.normal(0, 2.5e-3, size=(n, 128)).astype(np.float32)      # 1 - cos ~ 4e-4 inside a family
+    fam = (fam / np.linalg.norm(fam, axis=1, keepdims=True)).astype(np.float32)
+    d = _dev(torch, fam)
+    img = ops.pf_build_image(d, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6)
+    chosen = ops.pf_choose_format(d, img, 1.0 + 1e-6)
+    assert chosen.format == ops.PF_F16X2 and chosen.data is img.data
+    dq = _dev(torch, fam[rng.integers(0, n, size=nq)])
+    s0, i0 = ops.ip_topk(d, dq, k)
+    for image in (chosen, img.as_format(ops.PF_F16X1)):
+        s1, i1 = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, image=image)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))

@@ -1,4 +1,5 @@
-"""First contact of the split-image prefilter scan with the GPU: a few shapes against the fp32 scan, with timings."""
+"""The prefilter scan over each image arithmetic (f16x2, f16x1, bf16x3) and without an image: a few shapes against the fp32 scan, with
+timings.  usage: python tools/pf2_try.py [n,nq,k ...]"""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -9,11 +10,12 @@ def run(n, nq, k, reps=20):
     d = syn.device_database(n, 0, seed=0, device="cuda", normalize=True)
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     q = torch.randn((nq, 128), generator=g, device="cuda"); q = q / q.norm(dim=1, keepdim=True)
-    t = time.perf_counter(); img = ops.pf_build_image(d); torch.cuda.synchronize(); t_img = time.perf_counter() - t
+    torch.cuda.synchronize(); t = time.perf_counter(); img = ops.pf_build_image(d, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6); torch.cuda.synchronize(); t_img = time.perf_counter() - t
+    img3 = ops.pf_build_image(d, fmt=ops.PF_BF16X3)
     ws = torch.empty_like(ops.PrefilterWorkspace(d.device).get(n, nq, k))
     s0, i0 = ops.ip_topk(d, q, k)
     res = {}
-    for name, image in (("image", img), ("regs", None)):
+    for name, image in (("f16x2", img), ("f16x1", img.as_format(ops.PF_F16X1)), ("bf16x3", img3), ("regs", None)):
         s, i = ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, workspace=ws, image=image)
         torch.cuda.synchronize()
         ok = bool(torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32)))
@@ -32,8 +34,8 @@ def run(n, nq, k, reps=20):
             ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, workspace=ws, image=image, out=(s, i))
         torch.cuda.synchronize()
         res[name] = (ok, fl, float(np.median(ts)), (time.perf_counter() - t) / reps * 1e3)
-    print("n=%d nq=%d k=%d image build %.2f ms | " % (n, nq, k, t_img * 1e3) +
-          " | ".join("%s: identical=%s flagged=%d scan %.3f ms call %.3f ms" % ((nm,) + v) for nm, v in res.items()), flush=True)
+    print("n=%d nq=%d k=%d fp16 image build %.2f ms\n   " % (n, nq, k, t_img * 1e3) +
+          "\n   ".join("%s: identical=%s flagged=%d scan %.3f ms call %.3f ms" % ((nm,) + v) for nm, v in res.items()), flush=True)
 
 shapes = [(70_000, 100, 5), (300_000, 256, 10), (1_000_000, 256, 10), (1_000_000, 128, 10), (4_000_000, 256, 10), (1_000_000, 1024, 10), (1_000_000, 256, 32)]
 if len(sys.argv) > 1:

@@ -45,6 +45,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     static_assert(NQP == 1 || NQP == 2, "query parts");
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
     constexpr int PPW = 16 / NW;                       // LDS-DMA pieces of a tile per wave
+#ifdef MS_STAMP
+    const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tl_setup = 0, tl_first = 0, tl_loop = 0;
+#endif
     if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char_t;
@@ -469,6 +473,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
 
 #ifdef MS_STAMP
     const unsigned long long sp_c0 = __builtin_amdgcn_s_memtime(), sp_r0 = __builtin_amdgcn_s_memrealtime();
+    tl_setup = sp_r0;
 #endif
     if (ntl > 0) {
         // the first W tiles: own pieces, then (tile 0) everybody's.  With fewer than D tiles fewer pieces were issued: drain.
@@ -478,6 +483,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             if (t < ntl) publish(t);
         read_arrived(0);
         wait_arrived(0);
+#ifdef MS_STAMP
+        tl_first = __builtin_amdgcn_s_memrealtime();
+#endif
         {
             const f32x4 *src = frag_base(0);
 #pragma unroll
@@ -558,6 +566,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
 #ifdef MS_STAMP
         if (!SAMPLE && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
             unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;
+            tl_loop = __builtin_amdgcn_s_memrealtime();
             o[0] = __builtin_amdgcn_s_memtime() - sp_c0;
             o[1] = __builtin_amdgcn_s_memrealtime() - sp_r0;
             o[2] = (unsigned long long)ntl;
@@ -611,6 +620,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             p.part_i[o] = st.li[j];
         }
     }
+#ifdef MS_STAMP
+    if (!SAMPLE && lane == 0 && p.stamps != nullptr && bid < 4096) {      // timeline of this wave (100 MHz ticks, absolute): second half of the buffer
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long *o = p.stamps + 8 * 8 * 4096 + ((size_t)bid * 8 + wave) * 8;
+        o[0] = tl_entry; o[1] = tl_setup; o[2] = tl_first; o[3] = tl_loop; o[4] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
 }
 
 template <int KL, int NW, bool MASK, int NQP>

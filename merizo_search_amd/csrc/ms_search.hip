@@ -216,8 +216,11 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
-                                                             const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
+                                                             const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride, uint32_t *zero2) {
     if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    // (the merge in front of ms_rescore_kernel also zeroes that kernel's slot counter and ticket: whatever an aborted launch, or a
+    //  second stream on the same workspace, left there -- a stale ticket would silently keep the exact pass from running)
+    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int q = blockIdx.x;
     if (dp != nullptr) {
@@ -817,23 +820,23 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 // plan (pl.P is then its upper bound), query q of the compacted batch is output row qmap[q]
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st,
-                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0, size_t sm_stride = 0) {
+                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0, size_t sm_stride = 0, uint32_t *zero2 = nullptr) {
     const uint32_t *gate = sp.gate;
     const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
     const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
-    if (block_lds <= 156 * 1024 && pl.P <= 256 && (block_merge_setting() || dp != nullptr)) {     // the usual case: a workgroup per query
+    if (block_lds <= 156 * 1024 && pl.P <= 256 && (block_merge_setting() || dp != nullptr || zero2 != nullptr || sm_stride != 0)) {     // the usual case: a workgroup per query
         if (block_lds > 48 * 1024)
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0, sm_stride);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0, sm_stride, zero2);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
     if (dp != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the exact pass behind the prefilter needs the block merge (P = %d, k = %d)", pl.P, kp);
-    if (sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: stream-major lists need the block merge (P = %d, k = %d)", pl.P, kp);
+    if (sm_stride != 0 || zero2 != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the prefilter's candidate merge needs the block merge (P = %d, k = %d)", pl.P, kp);
     if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
@@ -1264,10 +1267,10 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         if (out_scores == nullptr || out_idx == nullptr) MS_FAIL(MS_ERR_ARG, "ms_ip_topk_prefiltered: NULL outputs");
         float *as = reinterpret_cast<float *>(ws + L.off_as);
         int64_t *ai = reinterpret_cast<int64_t *>(ws + L.off_ai);
-        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1,
-                          image != nullptr ? (size_t)pl.nq_pad * L.kp : 0);     // (sparse lists; stream-major behind the image scans)
-        if (rc) return rc;
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
+        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1,
+                          image != nullptr ? (size_t)pl.nq_pad * L.kp : 0, gate + 4);     // (sparse lists; stream-major behind the image scans)
+        if (rc) return rc;
         const uint32_t epoch = next_epoch();
         const ScanPlan &px = L.exact;
         uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.off_flag);
@@ -1278,7 +1281,6 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         PfCompact cp;
         cp.qn_c = qn_c; cp.lb_c = lb_c; cp.qlen_c = qlen_c; cp.qmap = qmap; cp.dp = dp; cp.gate = gate; cp.epoch = epoch; cp.n = n;
         cp.cus = cu_count_cached(); cp.nq = nq;
-        MS_HIP_CHECK(hipMemsetAsync(gate + 4, 0, 2 * sizeof(uint32_t), st));      // slot counter + ticket: zero whatever an aborted launch left
         hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, pf_err_coef(image != nullptr, format) * row_norm_bound,
                            (image != nullptr && format != MS_PF_BF16X3) ? 1 : 0,
                            lengths, qlen, mincov, out_scores, out_idx, flag, cp);

@@ -241,7 +241,7 @@ def pf_choose_format(db, image: PfImage, row_norm_bound: float, nsample: int = 2
     n = db.shape[0]
     if not prefilter_serves(n, max(nsample, 65), k):
         return image
-    idx = torch.linspace(0, n - 1, nsample, device=db.device).long()
+    idx = (torch.arange(nsample, dtype=torch.int64, device=db.device) * (n - 1)) // max(1, nsample - 1)      # (integers: float32 cannot count 45 M rows)
     q = db[idx].contiguous()
     ws = PrefilterWorkspace(db.device).get(n, nsample, k)
     ip_topk_prefiltered(db, q, k, row_norm_bound, mode=MODE_IP_NORMQ, workspace=ws, image=image.as_format(PF_F16X1))

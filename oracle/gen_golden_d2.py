@@ -5,7 +5,11 @@ squared-distance column of edge_mlp.0.weight at the scale of the other columns, 
 the first SiLU deep into saturation (pre-activations of +-1e2 .. +-1e3: the range SURVEY.md 7 warns about; the default
 fixtures scale that column by 1/64).  Writes tests/golden/egnn_d2.npz: coordinates and FoldClassNet embeddings.
 
-    python oracle/gen_golden_d2.py
+`long` (round 5): the same network on LONG chains -- random walks of 1000 and 2000 residues (2000 = createdb's truncation length,
+makedb.py:68-69), with d2_scale = 1.0 and with the default fixture weights -> tests/golden/egnn_long.npz (the reference materialises
+[N^2, 514] floats per layer: 8 GB and about a minute per structure at N = 2000).
+
+    python oracle/gen_golden_d2.py [long]
 """
 import os
 import sys
@@ -40,5 +44,25 @@ def main():
     np.savez_compressed(os.path.join(OUT, "egnn_d2.npz"), **arrays)
 
 
+def main_long():
+    arrays = {}
+    for tag, d2 in (("d2", 1.0), ("std", None)):
+        torch.manual_seed(0)
+        sd = W.synthetic_state_dict(0, d2_scale=d2) if d2 is not None else W.synthetic_state_dict(0)
+        net = FoldClassNet(128).eval()
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        with torch.no_grad():
+            for n, seed in ((1000, 1197), (2000, 2197)):
+                coords = syn.random_walk(n, seed=seed)
+                emb = net(torch.from_numpy(coords).unsqueeze(0))[0].numpy()
+                arrays[f"coords_walk{n}"] = coords
+                arrays[f"emb_{tag}_walk{n}"] = emb
+                print(tag, n, "max |e| = %.4g" % float(np.abs(emb).max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "egnn_long.npz"), **arrays)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        main_long()
+    else:
+        main()

@@ -17,7 +17,10 @@ ws = ops.TopKWorkspace(dev).get(n, nq, k)
 out_s = torch.empty((nq, k), dtype=torch.float32, device=dev); out_i = torch.empty((nq, k), dtype=torch.int64, device=dev)
 kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov)
 if "prefiltered" in sys.argv:
-    img = ops.pf_build_image(unit)
+    img = ops.pf_build_image(unit, row_norm_bound=1.0 + 1e-5)
+    if ops.pf_format_is_auto():
+        img = ops.pf_choose_format(unit, img, 1.0 + 1e-5)
+    print("image format:", {0: "bf16x3", 1: "f16x2", 2: "f16x1"}[img.format], flush=True)
     pws = ops.PrefilterWorkspace(dev).get(n, nq, k)
     for _ in range(reps):
         ops.ip_topk_prefiltered(unit, q, k, 1.0 + 1e-5, workspace=pws, image=img, out=(out_s, out_i), **kw)

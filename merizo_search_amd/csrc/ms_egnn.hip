@@ -675,11 +675,14 @@ __global__ __launch_bounds__(256) void ms_egnn_node_kernel(const NodeParams p) {
     {
         const float *src[NB];
         int cnt[NB], cmax = 0;
-        float m[NB];
+        // (float64 accumulator: a residue of a 2000-residue chain has 63 records, and the reference's own fp32 sums -- torch's
+        //  blocked reductions -- are within 1e-7 of the float64 truth there; a sequential fp32 sum is not: round 5, SURVEY.md 8c's
+        //  bar of 1e-6 at N = 2000)
+        double m[NB];
 #pragma unroll
         for (int nd = 0; nd < NB; ++nd) {
             const int g = g0 + nd;
-            src[nd] = p.part; cnt[nd] = 0; m[nd] = 0.0f;
+            src[nd] = p.part; cnt[nd] = 0; m[nd] = 0.0;
             if (g < p.total) {
                 const int d = p.node_dom[g];
                 const int off = p.offsets[d];
@@ -696,10 +699,10 @@ __global__ __launch_bounds__(256) void ms_egnn_node_kernel(const NodeParams p) {
         for (int q = 0; q < cmax; ++q) {
 #pragma unroll
             for (int nd = 0; nd < NB; ++nd)
-                if (q < cnt[nd]) m[nd] += src[nd][(size_t)q * MD];
+                if (q < cnt[nd]) m[nd] += (double)src[nd][(size_t)q * MD];
         }
 #pragma unroll
-        for (int nd = 0; nd < NB; ++nd) xs[nd][DIM + tid] = m[nd];
+        for (int nd = 0; nd < NB; ++nd) xs[nd][DIM + tid] = (float)m[nd];
     }
     __syncthreads();
     {   // node_mlp[0] + SiLU (:31-32): thread = output channel, all NB nodes
@@ -766,17 +769,17 @@ __global__ __launch_bounds__(128) void ms_egnn_pool_kernel(const float *__restri
     const int d = blockIdx.x, c = threadIdx.x;
     const int off = offsets[d], n = offsets[d + 1] - off;
     const float *src = h + (size_t)off * DIM + c;
-    float s = 0.0f;
+    double s = 0.0;          // (float64: 2000 sequential fp32 additions lose what the reference's blocked mean keeps)
     int i = 0;
     for (; i + 8 <= n; i += 8) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(i + u) * DIM];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) s += v[u];
+        for (int u = 0; u < 8; ++u) s += (double)v[u];
     }
-    for (; i < n; ++i) s += src[(size_t)i * DIM];
-    out[(size_t)d * DIM + c] = s / (float)n;
+    for (; i < n; ++i) s += (double)src[(size_t)i * DIM];
+    out[(size_t)d * DIM + c] = (float)(s / (double)n);
 }
 
 struct EgnnCarve {

@@ -2,16 +2,19 @@
 (FoldClassNet run on CPU with the same synthetic weights) and the CPU oracle.
 
 Floating point: the kernel restructures the first edge Linear and accumulates in a different
-order than torch, so parity is relative: max|delta| <= EGNN_REL * max|e| and cosine within
-1e-6 of 1 (SURVEY.md 8c measured 2e-8..1e-6 between two fp32 evaluations of this network;
-north_star: cosine scores within 1e-5)."""
+order than torch, so parity is relative: against the REFERENCE's goldens max|delta| <= EGNN_REL * max|e|
+with EGNN_REL = 1e-6, the criterion SURVEY.md 8c states (it measured 2e-8..1e-6 between two fp32
+evaluations of this network), and cosine within 1e-6 of 1 (north_star: cosine scores within 1e-5).
+Against the C oracle -- itself an fp32 evaluation 1.4e-7 .. 2.0e-7 away from the reference -- the bar is
+the sum of two such errors, ORACLE_REL = 2e-6."""
 import os
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-EGNN_REL = 1e-5
+EGNN_REL = 1e-6          # vs the reference's goldens (SURVEY.md 8c)
+ORACLE_REL = 2e-6        # vs the C oracle: two fp32 evaluations, each within EGNN_REL of the truth
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -65,7 +68,7 @@ def test_matches_oracle_on_ted_like_batch(encoder, synthetic_weights):
     e = encoder.embed(coords).cpu().numpy()
     ref = orc.egnn_embed(weights, pe, coords)
     for a, b in zip(e, ref):
-        _check(a, b)
+        _check(a, b, ORACLE_REL)
 
 
 def test_rejects_structures_longer_than_positional_table(encoder):
@@ -105,7 +108,26 @@ def test_embedding_with_a_large_distance_weight_saturated_silu(case, golden_dir)
     e = enc.embed([coords]).cpu().numpy()[0]
     assert np.isfinite(e).all()
     _check(e, g[f"emb_{case}"])
-    _check(e, orc.egnn_embed(weights, pe, [coords])[0])
+    _check(e, orc.egnn_embed(weights, pe, [coords])[0], ORACLE_REL)
+
+
+@pytest.mark.parametrize("n", [1000, 2000])
+@pytest.mark.parametrize("which", ["std", "d2"])
+def test_long_chains_match_the_reference_goldens(which, n, golden_dir):
+    """Chains of 1000 and 2000 residues (2000 = createdb's truncation length, makedb.py:68-69): 1M / 4M edges per layer, sums over
+    up to 2000 neighbours per residue -- with the default fixture weights and with the distance column at full scale (d2_scale = 1).
+    Reference goldens from oracle/gen_golden_d2.py long; the bar of SURVEY.md 8c, 1e-6 of max |e|, in the default (split-bf16) form."""
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn, weights as W
+    g = np.load(os.path.join(golden_dir, "egnn_long.npz"))
+    sd = W.synthetic_state_dict(0, d2_scale=1.0) if which == "d2" else W.synthetic_state_dict(0)
+    weights, pe = W.pack_state_dict(sd)
+    enc = ops.EgnnEncoder(weights, pe, "cuda:0")
+    coords = g[f"coords_walk{n}"]
+    assert np.array_equal(coords, syn.random_walk(n, seed={1000: 1197, 2000: 2197}[n]))
+    e = enc.embed([coords]).cpu().numpy()[0]
+    assert np.isfinite(e).all()
+    _check(e, g[f"emb_{which}_walk{n}"])
 
 
 def test_hundred_runs_of_a_ragged_batch_return_identical_bits(synthetic_weights):

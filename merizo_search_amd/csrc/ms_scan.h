@@ -69,6 +69,8 @@ struct ScanParams {
                                              // over the flagged queries of a prefiltered search); workgroups past its grid return at once
     const void *pf_image = nullptr;   // prefilter, ms_scan_pf.h / ms_scan_pf16.h: the image of db (ms_pf_build_image), or NULL (split in registers)
     int pf_format = 0;                // ... and its arithmetic: MS_PF_BF16X3 (32-row tiles), MS_PF_F16X2 / MS_PF_F16X1 (64-row tiles)
+    uint32_t *prog = nullptr;         // fp16-image scan with 2..16 query groups per row stream: [n_streams][16] progress words (epoch << 16 | tile),
+    uint32_t prog_epoch = 0;          // by which the workgroups of a stream keep within one L2 window of each other (ms_scan_pf16.h); NULL: off
     int qpw = 1;                      // ... and the waves per workgroup of that kernel, one query tile each, in fours (1: 4 waves, 2: 8)
     const uint32_t *gate = nullptr;   // NULL, or: the launch does nothing unless *gate == gate_epoch (the exact pipeline behind a
     uint32_t gate_epoch = 0;          // prefiltered search runs only when the prefilter could not prove its answer)
@@ -1846,7 +1848,7 @@ struct ScanPlan {
     int qpw;               // split-image prefilter scan (ms_scan_pf.h): query tiles per wave (0: any other kernel)
     size_t lds_bytes;
     // workspace carve (byte offsets)
-    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, total;
+    size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, off_prog, total;
 };
 
 inline int loader_wave_setting() {

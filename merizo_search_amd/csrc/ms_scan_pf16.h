@@ -293,6 +293,38 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         }
     };
     bool neg_tau = !SAMPLE && mask_on && (__ballot(st.tau < 0.0f) != 0);
+    // ---- pacing (several query groups per row stream: C4's 4096 queries are 16 workgroups on every stream, all on one XCD).  Left
+    //      alone they drift apart -- one visits the rare path more often, another loses the matrix pipe less -- and each then fetches
+    //      the stream's tiles from HBM for itself: 9.4 x the image per launch at the C4 shard (profiles/r05_pf_c4_pmc_free.json).
+    //      Wave 0 of every workgroup publishes its tile number every 16 tiles (one word per workgroup, the 16 words of a stream in
+    //      ONE 64-byte line; tagged with the launch's 8-bit epoch: no clearing between launches) and reads the line back with a SCALAR load
+    //      (glc: from the L2 all of them share; its own counter, so the vector-memory queue with the tiles in flight is not
+    //      drained): a workgroup more than PACE_LEAD tiles ahead of the slowest sleeps until it is not (bounded: pacing is an
+    //      optimisation, never a condition for progress).  The other waves of the workgroup follow through the arrival counters.
+    const bool pace_on = !SAMPLE && p.prog != nullptr;          // (uniform)
+    constexpr int PACE_LEAD = 48;
+    auto pace = [&](int t) __attribute__((always_inline)) {
+        if (wave != 0 || (t & 15) != 0) return;
+        const uint64_t line = (uint64_t)(uintptr_t)(p.prog + (size_t)stream * 16);
+        const uint32_t l_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)line), l_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(line >> 32));
+        const uint64_t sline = ((uint64_t)l_hi << 32) | (uint64_t)l_lo;
+        const uint32_t tag = p.prog_epoch << 24;                   // (8-bit epoch, 24-bit tile number: a stream has < 2^24 tiles)
+        if (lane == 0) __hip_atomic_store(p.prog + (size_t)stream * 16 + qg, tag | (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < PACE_LEAD) return;
+        typedef uint32_t u32x16_ __attribute__((ext_vector_type(16)));
+        for (uint32_t spins = 0; spins < 4096u; ++spins) {
+            u32x16_ w;
+            asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(sline) : "memory");
+            uint32_t mn = 0xFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const uint32_t v = ((w[i] >> 24) == p.prog_epoch) ? (w[i] & 0xFFFFFFu) : 0u;        // another launch's word: not started yet
+                if (i < p.n_qgroups) mn = v < mn ? v : mn;
+            }
+            if ((uint32_t)t <= mn + (uint32_t)PACE_LEAD) break;
+            __builtin_amdgcn_s_sleep(64);
+        }
+    };
     auto retau = [&]() __attribute__((always_inline)) { tau_s = st.tau * up; };
 
     // rare path: the candidates of tile t (scores sc_v) are counted and buffered; the lists take them later
@@ -535,6 +567,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         int t = 0;
         // the body of a stream: every stage issues (t + 1 + D < ntl), two tiles per iteration ...
         for (; t + 1 + PF2_D < ntl; t += 2) {
+            if (pace_on) pace(t);
             if (hist_on) hist_step(t);
             if constexpr (MS_PF16_SHADOW) {
                 stage(std::true_type{}, t, accA0, accA1, accB0, accB1);             // accA = scores of tile t - 1 (or -inf), accB <- tile t
@@ -574,6 +607,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             o[4] = sp_vis; o[5] = sp_nvis; o[6] = sp_chain; o[7] = (sp_hist << 32) | (sp_sync & 0xFFFFFFFFull);
         }
 #endif
+        if (pace_on && wave == 0 && lane == 0)        // this workgroup is through: nobody waits for it any more
+            __hip_atomic_store(p.prog + (size_t)stream * 16 + qg, (p.prog_epoch << 24) | 0xFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // drain: the last tile's scores (accA), rows past row_end rejected
         if (SAMPLE) {
             if (mask_on) { apply_mask(accA0, ntl - 1, 0); apply_mask(accA1, ntl - 1, 1); }

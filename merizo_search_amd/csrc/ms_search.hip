@@ -774,6 +774,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
     pl.off_scr_i = off;   off += ms_align_up((size_t)pl.nq_pad * pl.k_pass * sizeof(int64_t), 256);
     pl.off_hist = off;    off += ms_align_up((size_t)pl.nq_pad * 16 * sizeof(uint32_t), 256);
     pl.off_hstep = off;   off += ms_align_up((size_t)pl.nq_pad * sizeof(float), 256);
+    pl.off_prog = off;    off += qpw > 0 ? ms_align_up((size_t)pl.n_streams * 64, 256) : 0;      // progress words of the image scan's workgroups
     pl.total = off;
     return pl;
 }
@@ -1150,6 +1151,11 @@ namespace {
 // candidates kept per query: twice k for short lists, at least 8-16 spare entries for long ones (the proof needs the rows within the
 // error bound of the k-th best to fit; more spare entries = fewer queries for the exact pass on clustered data)
 int pf_list_len(int k) { return k <= 5 ? 10 : (k <= 10 ? 20 : (k <= 24 ? 32 : (k <= MS_PREFILTER_MAX_K ? 64 : 0))); }
+int pace_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_PF_PACE"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = the query groups of a row stream run free
+    return v;
+}
 int prefilter_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_PREFILTER"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the fp32 scan
@@ -1260,6 +1266,13 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
     if ((stages & 1) && (stages & 2) && sp.hist != nullptr) (void)hist_take_clean(workspace, n, nq, L.kp);
     sp.k = pl.k_pass;
     if (stages & 2) {
+        if (image != nullptr && format != MS_PF_BF16X3 && pl.n_qgroups >= 2 && pl.n_qgroups <= 16 && pace_setting()) {
+            // several query groups walk every row stream: they pace each other through progress words (ms_scan_pf16.h) so that a tile
+            // one of them fetched is still in the XCD's L2 when the others want it
+            static std::atomic<uint32_t> pace_epoch{1};
+            sp.prog = reinterpret_cast<uint32_t *>(ws + pl.off_prog);
+            sp.prog_epoch = pace_epoch.fetch_add(1) & 0xFFu;
+        }
         rc = launch_scan(pl, sp, st);
         if (rc) return rc;
     }

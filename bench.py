@@ -208,7 +208,8 @@ class SearchBench:
         shard: split image built once, the largest row norm measured once."""
         ops, dev = self.ops, self.db.device
         # (decided on the smallest shard so that every rank takes the same path: the steps contain collectives)
-        self.prefilter = bool(prefilter) and ops.prefilter_serves(self.n_total // self.world, self.nq, self.k)
+        self.prefilter = bool(prefilter) and (ops.prefilter_serves(self.n_total // self.world, self.nq, self.k) or
+                                              ops.prefilter_serves(self.n_total // self.world, self.nq, self.k, ops.pf_default_format()))
         if self.prefilter and self.image is None:
             self.row_norm_bound = float(1.0 / ops.row_inv_norms(self.db, 1e-30).min()) * (1.0 + 1e-6)
             self.image = ops.pf_build_image(self.db, row_norm_bound=self.row_norm_bound)     # (as the driver does: the fp16 image, then
@@ -217,6 +218,8 @@ class SearchBench:
             fmt_env = os.environ.get("MS_BENCH_PF_FORMAT")                                    # A/B runs: f16x1 over the same image
             if fmt_env:
                 self.image = self.image.as_format({"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1, "bf16x3": ops.PF_BF16X3}[fmt_env])
+        if self.prefilter and self.nq <= 32 and self.image.format == ops.PF_F16X1:
+            self.image = self.image.as_format(ops.PF_F16X2)       # (as the engine does for a few queries: the tighter arithmetic at the same HBM-bound speed)
         self.ws = self.torch.empty_like((ops.PrefilterWorkspace if self.prefilter else ops.TopKWorkspace)(dev).get(self.n_local, self.nq, self.k))
 
     def variant(self, prefilter):
@@ -234,7 +237,11 @@ class SearchBench:
             # (dbsearch.knn_exact(raw_queries=True)) -- F.normalize and, for a handful of queries, the merge inside the scan launch
             if events is not None:
                 events[0].record()
-            ops.ip_topk(self.db, self.q_raw, self.k, mode=ops.MODE_IP_NORMQ, row_offset=self.lo, workspace=self.ws, out=(ex.out_s, ex.out_i))
+            if self.prefilter:      # (>= ms_pf_few_min_rows() rows: the same call over the fp16 image -- half the bytes of the fp32 rows)
+                ops.ip_topk_prefiltered(self.db, self.q_raw, self.k, self.row_norm_bound, mode=ops.MODE_IP_NORMQ, row_offset=self.lo, workspace=self.ws,
+                                        out=(ex.out_s, ex.out_i), image=self.image)
+            else:
+                ops.ip_topk(self.db, self.q_raw, self.k, mode=ops.MODE_IP_NORMQ, row_offset=self.lo, workspace=self.ws, out=(ex.out_s, ex.out_i))
             if events is not None:
                 events[1].record()
             if self.exchange:
@@ -380,8 +387,34 @@ def hbm_regime(make, rows_list, log):
                         "step_frac_of_hbm_peak": 512.0 * rows / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq, b.k),
                         "note": "see notes.small_batch.nq%d" % nq})
             log("hbm_regime rows=%d nq=%d: call %.3f ms (%.1f%% of 8 TB/s), step %.3f ms (%.1f%%)" % (rows, nq, scan_ms, out[-1]["scan_frac_of_hbm_peak"] * 100, ms, out[-1]["step_frac_of_hbm_peak"] * 100))
+            few_image_entry(b, out[-1], reps, log)
             del b
     return out
+
+
+def few_image_entry(b, entry, reps, log):
+    """<= 64 queries over the fp16 image (ms_ip_topk_prefiltered serves them from ms_pf_few_min_rows() rows on): the same step reading 256 B
+    per row instead of 512 -- added to an hbm_regime entry as `image`."""
+    res = b.step(); b.fence()
+    bp = b.variant(True)
+    if not bp.prefilter:
+        return
+    for _ in range(3):
+        rp = bp.step()
+    bp.fence(); t0 = time.perf_counter()
+    for _ in range(reps):
+        rp = bp.step()
+    bp.fence()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    tq = b.torch
+    entry["image"] = {"format": pf_format_name(bp.ops, bp.image), "ms_per_step": ms, "queries_per_s": b.nq / ms * 1e3,
+                      "image_GBps": 256.0 * b.n_local / ms / 1e6, "image_frac_of_hbm_peak": 256.0 * b.n_local / (ms * 1e-3) / HBM_PEAK,
+                      "fp32_rows_equivalent_frac_of_hbm_peak": 512.0 * b.n_local / (ms * 1e-3) / HBM_PEAK,
+                      "identical_to_fp32": bool(tq.equal(rp[1], res[1]) and tq.equal(rp[0].view(tq.int32), res[0].view(tq.int32))),
+                      "exact_pass_queries": bp.ops.prefilter_flagged(bp.ws)}
+    log("   over the fp16 image (%s): step %.3f ms = %.1f%% of 8 TB/s reading 256 B per row, identical: %s" % (
+        entry["image"]["format"], ms, entry["image"]["image_frac_of_hbm_peak"] * 100, entry["image"]["identical_to_fp32"]))
+    del bp
 
 
 def _timed_stages(torch, step, steps, warm=10):
@@ -917,6 +950,8 @@ def main():
                               "step_frac_of_hbm_peak": 512.0 * C4_ROWS_PER_GPU / (ms * 1e-3) / HBM_PEAK, "kernel": scan_kernel_name(nq_, k),
                               "note": "see notes.small_batch.nq%d" % nq_})
                 log("hbm_regime rows=%d nq=%d: scan %.3f ms (%.1f%% of 8 TB/s)" % (C4_ROWS_PER_GPU, nq_, sc, small[-1]["scan_frac_of_hbm_peak"] * 100))
+                if use_pf:
+                    few_image_entry(b, small[-1], 6, log)
                 del b
             line["hbm_regime"] += small
             del big, r4

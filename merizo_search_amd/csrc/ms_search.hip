@@ -595,6 +595,12 @@ int block_merge_setting() {
     return v;
 }
 
+int64_t pf_few_min_rows() {         // <= 64 queries take the fp16-image scan from this many rows (MS_PF_FEW_MIN_ROWS overrides)
+    static int64_t v = -1;
+    if (v < 0) { const char *e = getenv("MS_PF_FEW_MIN_ROWS"); v = e ? atoll(e) : (int64_t)MS_PF_FEW_MIN_ROWS; }
+    return v;
+}
+
 int sample_min_queries_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_SAMPLE_MIN_NQ"); v = e ? atoi(e) : 8; }
@@ -759,7 +765,10 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
         pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));
     }
     if (tiles_per_stream < 8 * (int64_t)pl.prepass_tiles) pl.prepass_tiles = (int)(tiles_per_stream / 8);
-    if (tiles_per_stream < 12 || k > 64 || nq < sample_min_queries_setting()) pl.prepass_tiles = 0;   // short streams / few queries: few insertions anyway
+    // short streams / few queries: few insertions anyway -- except in the image scans of the prefilter, whose lists only take candidates at
+    // a flush and whose thresholds come from the sample and the shared bound alone: without a sample every tile visits the rare path
+    // until the first flush (one query over 1M rows: 158 us against 62 with a sample)
+    if (tiles_per_stream < 12 || k > 64 || (qpw == 0 && nq < sample_min_queries_setting())) pl.prepass_tiles = 0;
     if (qpw > 0 && tile_rows == 64) pl.prepass_tiles = (pl.prepass_tiles + 1) / 2;                     // (counted in the kernel's own tiles)
     size_t off = 0;
     pl.off_qn = off;      off += ms_align_up((size_t)pl.nq_pad * MS_DIM * sizeof(float), 256);
@@ -1002,6 +1011,7 @@ void ms_small_batch_thresholds(int *fused_merge_max_nq, int *inkernel_norm_max_n
     if (inkernel_norm_max_nq != nullptr) *inkernel_norm_max_nq = inkernel_norm_setting();
 }
 int ms_prefilter_max_k(void) { return MS_PREFILTER_MAX_K; }
+int64_t ms_pf_few_min_rows(void) { return pf_few_min_rows(); }
 
 int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stream) {
     if (d != MS_DIM) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows: d must be %d (got %d)", MS_DIM, d);
@@ -1187,7 +1197,10 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image, int format = 
     L.exact = make_plan(n, nq, k, cus);
     const bool ip = mode == MS_MODE_IP_PRENORM || mode == MS_MODE_IP_NORMQ;
     // without an image the rows are split in registers (round 3's kernel: inner-product modes only, the loader-wave form)
-    L.ok = prefilter_setting() && L.kp > 0 && n >= 65536 && L.exact.qwb == 4 &&
+    // (one or two query tiles -- the reference's own CLI regime -- are HBM-bound: over the fp16 image the scan reads half the bytes of
+    //  the fp32 rows; worth the fixed cost of the pipeline around it from a few million rows: pf_few_min_rows)
+    const bool few_ok = image && format != MS_PF_BF16X3 && n >= pf_few_min_rows();
+    L.ok = prefilter_setting() && L.kp > 0 && n >= 65536 && (L.exact.qwb == 4 || few_ok) &&
            (image ? (ip || mode == MS_MODE_COSINE_UNIT) : (ip && loader_wave_setting() != 0));
     L.exact_grid_max = L.exact.grid; L.exact_P_max = L.exact.P;
     if (!L.ok) { L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0; return L; }

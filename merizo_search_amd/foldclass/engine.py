@@ -58,6 +58,22 @@ class LazyPfImage:
     def built(self) -> bool:
         return self._built
 
+    def want(self, n: int, nq: int, k: int):
+        """The image for a batch of nq queries, building it when that pays: at once for a batch the prefilter serves without an
+        fp16 image (more than 64 queries), from the THIRD few-query search on a database large enough for the HBM-bound regime over
+        the image (one pass over the rows to build it = about one and a half searches) -- a CLI run with one or two query domains
+        never pays for it."""
+        if self._built:
+            return self._image
+        ops = self._engine._ops
+        if ops.prefilter_serves(n, nq, k):
+            return self.get()
+        if ops.prefilter_serves(n, nq, k, ops.pf_default_format()):
+            self._few = getattr(self, "_few", 0) + 1
+            if self._few >= 3:
+                return self.get()
+        return None
+
     def get(self):
         if not self._built:
             self._image = self._engine.pf_image(self._db, self._bound)
@@ -130,11 +146,10 @@ class HipEngine:
         """search_query_against_db's arithmetic on rows normalised once (cosine_rows).  pf_image (`pf_image(rows)`, built when the
         database became resident): batches of more than 64 queries take the prefiltered search, same results bit for bit."""
         ops = self._ops
-        if pf_image is not None and ops.prefilter_serves(rows.shape[0], q.shape[0], k):
-            image = pf_image.get() if isinstance(pf_image, LazyPfImage) else pf_image
-            if image is not None:
-                return ops.ip_topk_prefiltered(rows, q, k, self.UNIT_ROW_BOUND, mode=ops.MODE_COSINE_UNIT, row_offset=row_offset,
-                                               workspace=self._pws, image=image, lengths=lengths, qlen=qlen, mincov=mincov)
+        image = self._image_for(pf_image, rows.shape[0], q.shape[0], k)
+        if image is not None:
+            return ops.ip_topk_prefiltered(rows, q, k, self.UNIT_ROW_BOUND, mode=ops.MODE_COSINE_UNIT, row_offset=row_offset,
+                                           workspace=self._pws, image=image, lengths=lengths, qlen=qlen, mincov=mincov)
         return ops.ip_topk(rows, q, k, mode=ops.MODE_COSINE_UNIT, lengths=lengths, qlen=qlen, mincov=mincov,
                            row_offset=row_offset, workspace=self._ws)
 
@@ -146,11 +161,28 @@ class HipEngine:
         prefilter cannot prove get an exact pass of their own inside the same call: no feedback loop, no switch."""
         ops = self._ops
         mode = ops.MODE_IP_NORMQ if normalize_queries else ops.MODE_IP_PRENORM
-        if row_norm_bound is not None and ops.prefilter_serves(db.shape[0], q.shape[0], k):
-            image = pf_image.get() if isinstance(pf_image, LazyPfImage) else pf_image
+        image = self._image_for(pf_image, db.shape[0], q.shape[0], k) if row_norm_bound is not None else None
+        if row_norm_bound is not None and (image is not None or ops.prefilter_serves(db.shape[0], q.shape[0], k)):
             return ops.ip_topk_prefiltered(db, q, k, float(row_norm_bound), mode=mode, row_offset=row_offset, workspace=self._pws,
                                            image=image)
         return ops.ip_topk(db, q, k, mode=mode, row_offset=row_offset, workspace=self._ws)
+
+    def _image_for(self, pf_image, n: int, nq: int, k: int):
+        """The image this batch is searched over, or None (fp32 scan / rows split in registers).  Large batches: the database's
+        image in the arithmetic chosen for it.  <= 64 queries over an fp16 image of >= ms_pf_few_min_rows() rows: the HBM-bound regime
+        at half the bytes -- up to 32 queries with the tighter two-instruction arithmetic (the matrix pipe has time to spare there)."""
+        ops = self._ops
+        if pf_image is None:
+            return None
+        if isinstance(pf_image, LazyPfImage):
+            pf_image = pf_image.want(n, nq, k)
+            if pf_image is None:
+                return None
+        if not ops.prefilter_serves(n, nq, k, pf_image):
+            return None
+        if nq <= 32 and pf_image.format == ops.PF_F16X1:
+            return pf_image.as_format(ops.PF_F16X2)
+        return pf_image
 
     def pf_image(self, db, row_norm_bound=None, reserve: int = 6 << 30):
         """The prefilter's image of a resident matrix (ops.pf_build_image; the fp32 rows stay for the exact re-scoring): fp16 rows,

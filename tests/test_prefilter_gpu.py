@@ -432,3 +432,41 @@ def test_the_arithmetic_is_chosen_per_database_by_searching_its_own_rows(torch_g
     for image in (chosen, img.as_format(ops.PF_F16X1)):
         s1, i1 = ops.ip_topk_prefiltered(d, dq, k, 1.0 + 1e-6, image=image)
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+@pytest.mark.parametrize("image", ["f16x2", "f16x1"])
+@pytest.mark.parametrize("nq,k", [(1, 10), (3, 1), (17, 10), (32, 20), (33, 5), (64, 10)])
+def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, torch_gpu):
+    """The reference's own CLI regime (one to a few query domains per call, dbsearch.py:531-546) is HBM-bound: from ms_pf_few_min_rows()
+    rows on, ms_ip_topk_prefiltered serves ANY number of queries over an fp16 image -- 256 B per row instead of 512.  2.1M rows (the
+    threshold is 2M): indices and score bits == the oracle's; nothing flagged on ordinary data; below the threshold, or over a
+    split-bf16 image, the same call is ms_ip_topk (same answers)."""
+    torch = torch_gpu
+    from merizo_search_amd import ops, _lib
+    from oracle import oracle as orc
+    assert int(_lib.load().ms_pf_few_min_rows()) == 1_000_000
+    n = 1_050_000
+    db, q = _norm_db(n, seed=561), _norm_db(nq, seed=562 + nq)
+    assert ops.prefilter_serves(n, nq, k, {"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1}[image]) and not ops.prefilter_serves(n, nq, k)
+    assert not ops.prefilter_serves(n, nq, k, ops.PF_BF16X3) and not ops.prefilter_serves(990_000, nq, k, ops.PF_F16X2)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=9, raw=(nq % 2 == 1), expect_fallback=False, image=image)
+
+
+def test_engine_builds_the_image_for_few_query_searches_from_the_third_call(torch_gpu):
+    """foldclass/engine.py: a resident database of >= ms_pf_few_min_rows() rows searched with a handful of queries per call (the CLI's
+    loop over query structures) gets its fp16 image at the third such search -- one pass over the rows -- and every later search
+    reads half the bytes; results identical to the fp32 scan before and after."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import engine as eng, synthetic as syn
+    e = eng.HipEngine("cuda:0")
+    d = syn.device_database(1_200_000, 0, seed=571, device="cuda:0")
+    dq = syn.device_database(4, 0, seed=572, device="cuda:0") * 2.0
+    bound = e.row_norm_bound(d)
+    lazy = e.lazy_pf_image(d, bound)
+    s0, i0 = ops.ip_topk(d, dq, 10, mode=ops.MODE_IP_NORMQ)
+    for call in range(5):
+        s1, i1 = e.ip_topk(d, dq, 10, normalize_queries=True, row_norm_bound=bound, pf_image=lazy)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+        assert lazy.built == (call >= 2)
+    assert lazy.get().format in (ops.PF_F16X1, ops.PF_F16X2)

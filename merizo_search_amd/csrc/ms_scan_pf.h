@@ -93,7 +93,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const Scan
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
-    typedef volatile __attribute__((address_space(3))) ms_u32x4 lds_flag4_t;
     typedef __attribute__((address_space(3))) ms_u32x2 lds_cand_t;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -213,15 +213,10 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 // the workgroup's first wave.
 // dp / qmap (the exact pass over the flagged queries of a prefiltered search): the number of queries and of lists comes from the
 // device plan, and query q of the compacted batch is row qmap[q] of the outputs.
-__global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
-                                                             int64_t row_offset, float *out_s, int64_t *out_i,
-                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
-                                                             const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride, uint32_t *zero2) {
-    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
-    // (the merge in front of ms_rescore_kernel also zeroes that kernel's slot counter and ticket: whatever an aborted launch, or a
-    //  second stream on the same workspace, left there -- a stale ticket would silently keep the exact pass from running)
-    if (zero2 != nullptr && blockIdx.x == 0 && threadIdx.x < 2) zero2[threadIdx.x] = 0u;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void ms_block_merge_body(char *smem, const float *part_s, const uint32_t *part_i, int P, int k,
+                                                    int64_t row_offset, float *out_s, int64_t *out_i,
+                                                    int out_stride, int out_col0, float *ub_s, uint32_t *ub_i,
+                                                    const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
     int q = blockIdx.x;
     if (dp != nullptr) {
         if (q >= dp->nq) return;
@@ -323,6 +318,15 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
     }
 }
 
+__global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
+                                                             int64_t row_offset, float *out_s, int64_t *out_i,
+                                                             int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
+                                                             const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
+    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ms_block_merge_body(smem, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, dp, qmap, sparse, sm_stride);
+}
+
 // ------------------------------------------------------------------ sample bound -------
 // Lower bound of the full pass from the sample pass's lists: the k-th largest (with multiplicity) of the first
 // `ranks` entries of all P lists of a query -- scores of distinct rows, so at least k rows score >= the result.
@@ -400,88 +404,123 @@ struct PfCompact {
     int64_t n;
     int cus, nq;
 };
-__global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const float *qn, int k, int kp, const float *as,
-                                                        const int64_t *ai, int64_t row_offset, float err_coef, int fp16_range, const float *lengths,
-                                                        const float *qlen, float mincov, float *out_s, int64_t *out_i, uint32_t *flag,
-                                                        const PfCompact cp) {
+// The two counters of the compaction (slot counter, ticket) are plain atomic adds -- 256 workgroups arrive within a few
+// microseconds, and a compare-and-swap loop per arrival (tried: counters tagged with the call's epoch, so that no state could
+// survive an aborted launch) serialises them into O(n^2) retries: +250 us at C2.  The LAST workgroup of the launch zeroes both
+// for the next call; a workspace serves one stream at a time (include/merizo_search_amd.h), and a launch that aborts leaves the
+// HIP context in a sticky error anyway.
+struct PfRescore {
+    const float *db, *qn, *as;
+    const int64_t *ai;
+    const float *lengths, *qlen;
+    float *out_s;
+    int64_t *out_i;
+    uint32_t *flag;
+    int64_t row_offset;
+    float err_coef, mincov;
+    int k, kp, fp16_range;
+    PfCompact cp;
+};
+// Every thread of the workgroup calls it (barriers inside); the first wave does the work.  `coherent`: the candidate lists were
+// written by THIS workgroup a moment ago (the fused merge + re-scoring launch): read them past the L1.
+__device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int tid, bool coherent) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
     __shared__ float kth;
-    const int q = blockIdx.x, lane = threadIdx.x;
-    qs[lane] = qn[(size_t)q * MS_DIM + lane];
-    qs[64 + lane] = qn[(size_t)q * MS_DIM + 64 + lane];
-    if (lane == 0) kth = -INFINITY;
-    __syncthreads();
-    float qq = qs[lane] * qs[lane] + qs[64 + lane] * qs[64 + lane];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off);
-    const float qnorm = sqrtf(qq) * 1.001f;
-    const int64_t row = lane < kp ? ai[(size_t)q * kp + lane] : -1;
-    const bool full = ai[(size_t)q * kp + kp - 1] >= 0;
-    const float a_last = as[(size_t)q * kp + kp - 1];
-    float s = -INFINITY;
-    if (row >= 0) {
-        const float4 *x = reinterpret_cast<const float4 *>(db + (size_t)row * MS_DIM);
-        float acc = 0.0f;
-        // (the whole row requested before the chain starts: four batches of eight loads, each a round trip to a row nobody has
-        //  touched, were most of this kernel's 14 us)
-        float4 xl[16], xh[16];
-#pragma unroll
-        for (int t = 0; t < 16; ++t) { xl[t] = x[t]; xh[t] = x[16 + t]; }
-        __builtin_amdgcn_sched_barrier(0);          // (or hipcc pulls the loads back next to their uses, eight at a time)
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float4 lo = xl[t], hi = xh[t];
-            acc = fmaf(lo.x, qs[4 * t + 0], acc); acc = fmaf(hi.x, qs[64 + 4 * t + 0], acc);
-            acc = fmaf(lo.y, qs[4 * t + 1], acc); acc = fmaf(hi.y, qs[64 + 4 * t + 1], acc);
-            acc = fmaf(lo.z, qs[4 * t + 2], acc); acc = fmaf(hi.z, qs[64 + 4 * t + 2], acc);
-            acc = fmaf(lo.w, qs[4 * t + 3], acc); acc = fmaf(hi.w, qs[64 + 4 * t + 3], acc);
-        }
-        s = acc;
-        if (lengths != nullptr) {       // MS_MODE_COSINE_UNIT: the fp32 scan's own two multiplications (unit rows: scale 1; dbsearch.py:76,78)
-            float sv = s * 1.0f;
-            const float mk = (qlen[q] >= lengths[row] * mincov) ? 1.0f : 0.0f;
-            sv = sv * mk;
-            s = sv;
-        }
-    }
-    cs[lane] = s;
-    ci[lane] = row >= 0 ? (uint32_t)row : MS_IDX_NONE;
-    __syncthreads();
-    const int nvalid = __popcll(__ballot(row >= 0));
-    int rank = 0;
-    for (int j = 0; j < kp; ++j) rank += (ci[j] != MS_IDX_NONE && ms_better(cs[j], ci[j], s, ci[lane])) ? 1 : 0;
-    const size_t o0 = (size_t)q * k;
-    if (row >= 0 && rank < k) { out_s[o0 + rank] = s; out_i[o0 + rank] = row_offset + row; }
-    if (lane < k && lane >= nvalid) { out_s[o0 + lane] = -INFINITY; out_i[o0 + lane] = -1; }
-    if (row >= 0 && rank == k - 1) kth = s;
-    __syncthreads();
     __shared__ int slot_s;
-    if (lane == 0) {
+    const bool act = tid < 64;
+    const int lane = tid & 63;
+    const int k = a.k, kp = a.kp;
+    const PfCompact &cp = a.cp;
+    if (act) {
+        qs[lane] = a.qn[(size_t)q * MS_DIM + lane];
+        qs[64 + lane] = a.qn[(size_t)q * MS_DIM + 64 + lane];
+        if (lane == 0) kth = -INFINITY;
+    }
+    __syncthreads();
+    float qnorm = 0.0f, a_last = 0.0f, s = -INFINITY;
+    int64_t row = -1;
+    bool full = false;
+    if (act) {
+        float qq = qs[lane] * qs[lane] + qs[64 + lane] * qs[64 + lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) qq += __shfl_xor(qq, off);
+        qnorm = sqrtf(qq) * 1.001f;
+        const int64_t *aq = a.ai + (size_t)q * kp;
+        const float *sq = a.as + (size_t)q * kp;
+        if (coherent) {
+            row = lane < kp ? __hip_atomic_load(aq + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+            full = __hip_atomic_load(aq + kp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+            a_last = __hip_atomic_load(sq + kp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            row = lane < kp ? aq[lane] : -1;
+            full = aq[kp - 1] >= 0;
+            a_last = sq[kp - 1];
+        }
+        if (row >= 0) {
+            const float4 *x = reinterpret_cast<const float4 *>(a.db + (size_t)row * MS_DIM);
+            float acc = 0.0f;
+            // (the whole row requested before the chain starts: four batches of eight loads, each a round trip to a row nobody has
+            //  touched, were most of this kernel's 14 us)
+            float4 xl[16], xh[16];
+#pragma unroll
+            for (int t = 0; t < 16; ++t) { xl[t] = x[t]; xh[t] = x[16 + t]; }
+            __builtin_amdgcn_sched_barrier(0);          // (or hipcc pulls the loads back next to their uses, eight at a time)
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float4 lo = xl[t], hi = xh[t];
+                acc = fmaf(lo.x, qs[4 * t + 0], acc); acc = fmaf(hi.x, qs[64 + 4 * t + 0], acc);
+                acc = fmaf(lo.y, qs[4 * t + 1], acc); acc = fmaf(hi.y, qs[64 + 4 * t + 1], acc);
+                acc = fmaf(lo.z, qs[4 * t + 2], acc); acc = fmaf(hi.z, qs[64 + 4 * t + 2], acc);
+                acc = fmaf(lo.w, qs[4 * t + 3], acc); acc = fmaf(hi.w, qs[64 + 4 * t + 3], acc);
+            }
+            s = acc;
+            if (a.lengths != nullptr) {       // MS_MODE_COSINE_UNIT: the fp32 scan's own two multiplications (unit rows: scale 1; dbsearch.py:76,78)
+                float sv = s * 1.0f;
+                const float mk = (a.qlen[q] >= a.lengths[row] * a.mincov) ? 1.0f : 0.0f;
+                sv = sv * mk;
+                s = sv;
+            }
+        }
+        cs[lane] = s;
+        ci[lane] = row >= 0 ? (uint32_t)row : MS_IDX_NONE;
+    }
+    __syncthreads();
+    if (act) {
+        const int nvalid = __popcll(__ballot(row >= 0));
+        int rank = 0;
+        for (int j = 0; j < kp; ++j) rank += (ci[j] != MS_IDX_NONE && ms_better(cs[j], ci[j], s, ci[lane])) ? 1 : 0;
+        const size_t o0 = (size_t)q * k;
+        if (row >= 0 && rank < k) { a.out_s[o0 + rank] = s; a.out_i[o0 + rank] = a.row_offset + row; }
+        if (lane < k && lane >= nvalid) { a.out_s[o0 + lane] = -INFINITY; a.out_i[o0 + lane] = -1; }
+        if (row >= 0 && rank == k - 1) kth = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
         // (kth: k rows score at least this -- the bound the exact scan starts from, should it have to run (-inf: none): lb_c below)
         // (a list that is not full cannot happen on a database of >= 65,536 rows unless rows were lost to a bound: no proof then either)
         // (fp16 formats: the scan scales every query into the fp16 range by a power of two it clamps at 2^+-60 -- a query whose norm is
         //  outside [2^-40, 2^40] is not covered by the error bound: no proof)
-        const bool in_range = !fp16_range || (qnorm >= 9.094947e-13f && qnorm <= 1.0995116e12f);
-        const bool flagged = !full || !in_range || !(kth > a_last + err_coef * qnorm);
-        flag[q] = flagged ? 1u : 0u;
+        const bool in_range = !a.fp16_range || (qnorm >= 9.094947e-13f && qnorm <= 1.0995116e12f);
+        const bool flagged = !full || !in_range || !(kth > a_last + a.err_coef * qnorm);
+        a.flag[q] = flagged ? 1u : 0u;
         int slot = -1;
         if (flagged) {
             slot = (int)atomicAdd(cp.gate + 4, 1u);
             cp.qmap[slot] = q;
             cp.lb_c[slot] = kth;
-            cp.qlen_c[slot] = qlen != nullptr ? qlen[q] : 0.0f;
+            cp.qlen_c[slot] = a.qlen != nullptr ? a.qlen[q] : 0.0f;
         }
         slot_s = slot;
     }
     __syncthreads();
     const int slot = slot_s;
-    if (slot >= 0) {
+    if (act && slot >= 0) {
         cp.qn_c[(size_t)slot * MS_DIM + lane] = qs[lane];
         cp.qn_c[(size_t)slot * MS_DIM + 64 + lane] = qs[64 + lane];
     }
-    if (lane == 0) {
+    if (tid == 0) {
         __threadfence();                                         // (this workgroup's slot is taken before its ticket)
         const uint32_t done = atomicAdd(cp.gate + 5, 1u);
         if (done == (uint32_t)cp.nq - 1u) {                     // the last workgroup: every flagged query has its slot
@@ -498,6 +537,17 @@ __global__ __launch_bounds__(64) void ms_rescore_kernel(const float *db, const f
             cp.gate[5] = 0u;
         }
     }
+}
+// ONE launch for the prefilter's candidate merge and the exact re-scoring behind it (round 5; two launches and a clearing memset
+// before): a workgroup merges the per-stream lists of its query into the kp candidates (ms_block_merge_body: the sparse pool, or
+// the general merge), then its first wave re-scores them, ranks them, proves the answer or takes a slot of the exact pass.
+__global__ __launch_bounds__(256) void ms_merge_rescore_kernel(const float *part_s, const uint32_t *part_i, int P, float *as, int64_t *ai,
+                                                               size_t sm_stride, const PfRescore a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    ms_block_merge_body(smem, part_s, part_i, P, a.kp, 0, as, ai, a.kp, 0, nullptr, nullptr, nullptr, nullptr, 1, sm_stride);
+    __threadfence_block();
+    __syncthreads();
+    ms_rescore_body(a, (int)blockIdx.x, (int)threadIdx.x, true);
 }
 
 // ------------------------------------------------------------------ public k-way merge -
@@ -718,7 +768,6 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
     pl.qpw = qpw;
     pl.k_pass = k < 64 ? k : 64;
     pl.kl = pick_kl(pl.k_pass);
-    const int64_t tiles = (n + 31) / 32;
     int64_t tiles_per_stream;
     if (qpw == 0) {
         ScanDevPlan d;
@@ -830,23 +879,23 @@ int launch_scan(const ScanPlan &pl, const ScanParams &sp, hipStream_t st) {
 // plan (pl.P is then its upper bound), query q of the compacted batch is output row qmap[q]
 int launch_merge(const ScanPlan &pl, const ScanParams &sp, int nq, int kp, int64_t row_offset, float *out_s,
                  int64_t *out_i, int out_stride, int col0, float *ub_s, uint32_t *ub_i, hipStream_t st,
-                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0, size_t sm_stride = 0, uint32_t *zero2 = nullptr) {
+                 const ScanDevPlan *dp = nullptr, const int *qmap = nullptr, int sparse = 0, size_t sm_stride = 0) {
     const uint32_t *gate = sp.gate;
     const uint32_t gate_epoch = sp.gate_epoch;
     if (pl.P > MERGE_MAX_P) MS_FAIL(MS_ERR_RANGE, "internal: %d partial lists exceed the merge limit", pl.P);
     const size_t head_lds = (size_t)kp * pl.P * sizeof(uint2);
     const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
-    if (block_lds <= 156 * 1024 && pl.P <= 256 && (block_merge_setting() || dp != nullptr || zero2 != nullptr || sm_stride != 0)) {     // the usual case: a workgroup per query
+    if (block_lds <= 156 * 1024 && pl.P <= 256 && (block_merge_setting() || dp != nullptr || sm_stride != 0)) {     // the usual case: a workgroup per query
         if (block_lds > 48 * 1024)
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_block_merge_kernel),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_block_merge_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, kp, row_offset, out_s,
-                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0, sm_stride, zero2);
+                           out_i, out_stride, col0, ub_s, ub_i, gate, gate_epoch, dp, qmap, (ub_s == nullptr) ? sparse : 0, sm_stride);
         MS_LAUNCH_CHECK("ms_block_merge_kernel");
         return MS_OK;
     }
     if (dp != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the exact pass behind the prefilter needs the block merge (P = %d, k = %d)", pl.P, kp);
-    if (sm_stride != 0 || zero2 != nullptr) MS_FAIL(MS_ERR_RANGE, "internal: the prefilter's candidate merge needs the block merge (P = %d, k = %d)", pl.P, kp);
+    if (sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: stream-major lists need the block merge (P = %d, k = %d)", pl.P, kp);
     if (head_lds <= 128 * 1024 && head_merge_setting()) {       // k * P entries fit in LDS: one wave per query, k arg-max rounds
         const int per = (pl.P + 63) / 64;
 #define MS_HEAD_MERGE(PER)                                                                                             \
@@ -1216,7 +1265,7 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image, int format = 
         if (d.P > L.exact_P_max) L.exact_P_max = d.P;
         if ((size_t)d.nq_pad * d.P > lists_max) lists_max = (size_t)d.nq_pad * d.P;
     }
-    if (L.exact_P_max > 256 || L.pf.P > 256) {       // the merges behind the image scan and the exact pass stage <= 256 lists per query (a device with more than 256 CUs): ms_ip_topk
+    if (L.exact_P_max > 256 || L.pf.P > 256 || nq >= (1 << 20)) {       // the merges behind the image scan and the exact pass stage <= 256 lists per query (a device with more than 256 CUs): ms_ip_topk
         L.ok = false;
         L.total = L.exact.total; L.off_as = L.off_ai = L.off_flag = L.off_qn_c = L.off_lb_c = L.off_qlen_c = L.off_qmap = L.off_dp = L.off_xs = L.off_xi = 0;
         return L;
@@ -1294,9 +1343,6 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         float *as = reinterpret_cast<float *>(ws + L.off_as);
         int64_t *ai = reinterpret_cast<int64_t *>(ws + L.off_ai);
         uint32_t *gate = reinterpret_cast<uint32_t *>(blk + 256);
-        rc = launch_merge(pl, sp, nq, L.kp, 0, as, ai, L.kp, 0, nullptr, nullptr, st, nullptr, nullptr, 1,
-                          image != nullptr ? (size_t)pl.nq_pad * L.kp : 0, gate + 4);     // (sparse lists; stream-major behind the image scans)
-        if (rc) return rc;
         const uint32_t epoch = next_epoch();
         const ScanPlan &px = L.exact;
         uint32_t *flag = reinterpret_cast<uint32_t *>(ws + L.off_flag);
@@ -1307,10 +1353,18 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         PfCompact cp;
         cp.qn_c = qn_c; cp.lb_c = lb_c; cp.qlen_c = qlen_c; cp.qmap = qmap; cp.dp = dp; cp.gate = gate; cp.epoch = epoch; cp.n = n;
         cp.cus = cu_count_cached(); cp.nq = nq;
-        hipLaunchKernelGGL(ms_rescore_kernel, dim3(nq), dim3(64), 0, st, db, sp.qn, k, L.kp, as, ai, row_offset, pf_err_coef(image != nullptr, format) * row_norm_bound,
-                           (image != nullptr && format != MS_PF_BF16X3) ? 1 : 0,
-                           lengths, qlen, mincov, out_scores, out_idx, flag, cp);
-        MS_LAUNCH_CHECK("ms_rescore_kernel");
+        // ONE launch: merge of the per-stream candidate lists (sparse; stream-major behind the image scans) + exact re-scoring + proof + compaction
+        PfRescore ra;
+        ra.db = db; ra.qn = sp.qn; ra.as = as; ra.ai = ai; ra.lengths = lengths; ra.qlen = qlen; ra.out_s = out_scores; ra.out_i = out_idx; ra.flag = flag;
+        ra.row_offset = row_offset; ra.err_coef = pf_err_coef(image != nullptr, format) * row_norm_bound; ra.mincov = mincov;
+        ra.k = k; ra.kp = L.kp; ra.fp16_range = (image != nullptr && format != MS_PF_BF16X3) ? 1 : 0; ra.cp = cp;
+        const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)L.kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
+        if (block_lds > 156 * 1024 || pl.P > 256) MS_FAIL(MS_ERR_RANGE, "internal: %d candidate lists of %d entries exceed the merge", pl.P, L.kp);
+        if (block_lds > 48 * 1024)
+            MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_merge_rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
+        hipLaunchKernelGGL(ms_merge_rescore_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, as, ai,
+                           image != nullptr ? (size_t)pl.nq_pad * L.kp : (size_t)0, ra);
+        MS_LAUNCH_CHECK("ms_merge_rescore_kernel");
         // The exact pass, for the flagged queries ONLY (the reference's semantics are per query: dbsearch.py:234-242): an fp32 scan
         // and a merge over the compacted batch, decomposed on the device (ScanDevPlan), both returning at once when no query was
         // flagged.  No sample pass: the k-th best exact score among a query's candidates is already a lower bound on its k-th

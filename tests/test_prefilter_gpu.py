@@ -470,3 +470,22 @@ def test_engine_builds_the_image_for_few_query_searches_from_the_third_call(torc
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
         assert lazy.built == (call >= 2)
     assert lazy.get().format in (ops.PF_F16X1, ops.PF_F16X2)
+
+
+@pytest.mark.parametrize("nq", [1, 6, 40])
+def test_few_queries_cosine_with_length_mask_over_the_fp16_image(nq, torch_gpu):
+    """search_query_against_db's shape -- ONE query (or a few) against a `.pt` database normalised once, cosine + length mask
+    (dbsearch.py:75-81) -- over the fp16 image of 1.05M unit rows: == the fp32 scan bit for bit, both arithmetics."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    n, k = 1_050_000, 10
+    db, q, lengths, qlen = _cosine_case(n, nq, seed=580 + nq)
+    d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
+    unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
+    kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=0.7)
+    s0, i0 = ops.ip_topk(unit, dq, k, row_offset=3, **kw)
+    img = _img(ops, unit, "f16x2", 1.0 + 1e-5)
+    ws = ops.PrefilterWorkspace(d.device).get(n, nq, k)
+    for image in (img, img.as_format(ops.PF_F16X1)):
+        s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, row_offset=3, workspace=ws, image=image, **kw)
+        assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))

@@ -93,9 +93,9 @@ def small_batch_note(nq, ops=None):
 
 
 PF_FORMATS = {   # name -> (matrix instructions per 16 dimensions, image bytes per row, matrix instruction, dtype label)
-    "f16x2": (2, 256.0, "v_mfma_f32_32x32x16_f16", "f16x2 scan (fp16 rows x split fp16 queries) + f32 re-score"),
-    "f16x1": (1, 256.0, "v_mfma_f32_32x32x16_f16", "f16x1 scan (fp16 rows x fp16 queries) + f32 re-score"),
-    "bf16x3": (3, 512.0, "v_mfma_f32_32x32x16_bf16", "bf16x3-split scan + f32 re-score"),
+    "f16x2": (2, 256.0, "v_mfma_f32_32x32x16_f16", "f16x2 image scan + f32 re-score"),        # fp16 rows x split fp16 queries
+    "f16x1": (1, 256.0, "v_mfma_f32_32x32x16_f16", "f16x1 image scan + f32 re-score"),        # fp16 rows x fp16 queries
+    "bf16x3": (3, 512.0, "v_mfma_f32_32x32x16_bf16", "bf16x3 image scan + f32 re-score"),     # bf16 hi + lo of rows and queries
 }
 
 
@@ -466,7 +466,7 @@ def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
            "roofline": roofline(nq, n, k, scan_ms, ms)}
     out["roofline"]["kernel"] = "ms_scan_loader_kernel<5, 2> (unit-row cosine variant: in-chain filter on the final scores, length mask in the rare path)"
     out["roofline"]["algorithmic_bytes_per_launch"] = 516.0 * n          # rows + their lengths
-    attach_committed_traffic(out["roofline"], "r04_c3_pmc.json")
+    attach_committed_traffic(out["roofline"], "r05_c3_pmc.json")
     log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
     state = {"unit": unit, "lengths": lengths, "mincov": mincov, "n": n, "k": k, "image": None, "pws": None}
     if prefilter and ops.prefilter_serves(n, nq, k):
@@ -695,6 +695,11 @@ def compact_line(doc, full_path=None):
     hb = doc.get("hbm_regime")
     if hb:
         more["hbm_regime_step_frac"] = {"%dM_nq%d" % (round(e["rows"] / 1e6), e["nq"]): _r(float("%.3g" % e["step_frac_of_hbm_peak"])) for e in hb}
+        # the same steps over the fp16 image (256 B per row): fraction of the HBM peak in IMAGE bytes, and the speed-up over the fp32 rows
+        img = {"%dM_nq%d" % (round(e["rows"] / 1e6), e["nq"]): [_r(float("%.3g" % e["image"]["image_frac_of_hbm_peak"])), _r(float("%.3g" % (e["ms_per_step"] / e["image"]["ms_per_step"])))]
+               for e in hb if e.get("image")}
+        if img:
+            more["hbm_regime_fp16_image_frac_and_speedup"] = img
     em = doc.get("embed")
     if em:
         more["embed"] = {"embeds_per_s": _r(em["embeds_per_s"]), "frac": _r(em["roofline"]["frac"])}
@@ -857,7 +862,7 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
         if c2:
-            attach_committed_traffic(roof, "r04_c2_pmc.json")
+            attach_committed_traffic(roof, "r05_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
         elif world == 1 and args.shape == "c4":
@@ -927,7 +932,7 @@ def main():
                                         "(a projection: no multi-GPU node was available to this build)",
                                 "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
             if k == 10:
-                attach_committed_traffic(line["c4_shard"]["roofline"], "r04_c4_pmc.json")
+                attach_committed_traffic(line["c4_shard"]["roofline"], "r05_c4_pmc.json")
             log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (fp32 scan %.1f ms = %.1f%% of fp32 MFMA peak)" % (ms4, C4_NQ / ms4 * 1e3, sc, line["c4_shard"]["roofline"]["frac"] * 100))
             if use_pf:
                 line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r05_pf_c4_pmc.json" if k == 10 else None)

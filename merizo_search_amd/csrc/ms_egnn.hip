@@ -305,6 +305,7 @@ struct EdgeParams {
     float *part;                  // [records][256]
     int nb;
     int total;
+    int n_tiles;                  // tiles of this launch (split form with 8 waves: a workgroup takes two; the last one may have one)
 #ifdef MS_STAMP
     unsigned long long *stamps;   // diagnostic builds: per tile phase cycles
 #endif
@@ -322,7 +323,24 @@ struct EdgeParams {
 // cluster behind the stage's 160 MFMAs, kept there by a scheduling fence (hipcc would spread it through the MFMAs).
 constexpr int W_STAGE_F4 = STAGE_G * 8 * 64;                      // float4 per W2 stage (40 KiB)
 constexpr int EDGE_LDS = 2 * W_STAGE_F4 * 16;                     // two ring slots: 80 KiB per workgroup, two workgroups per CU
-constexpr int EDGE_LDS_SPLIT = 3 * W2S_BLOCK_BYTES;               // split form: three slots of one k block (24 KiB) each: 72 KiB
+#ifndef MS_EGNN_W8
+#define MS_EGNN_W8 0            // round 5 A/B (profiles/r05_egnn_variants_ab.log): the 8-wave workgroup is correct and no faster (58.2-58.3 against 57.4-57.9 ms)
+#endif
+#ifndef MS_EGNN_BPREFETCH
+#define MS_EGNN_BPREFETCH 1
+#endif
+#ifndef MS_EGNN_LOAD_NT
+#define MS_EGNN_LOAD_NT 4       // the channel tile of a k block behind which the projections of block b + 2 are requested: their registers are free
+                                // from tile 4 on, and three tiles more of lead cover the L2 round trip (tile 7, round 4: 59.1 -> 57.7 ms)
+#endif
+// split form, MS_EGNN_W8=1 (round 5, built, parity-green, NOT the default): ONE workgroup of EIGHT waves per CU -- two 128-edge tiles side
+// by side (waves 0-3 / 4-7) over ONE W2S ring of six 24 KiB slots, a barrier every SECOND k block, every W2S block crossing L2 -> LDS
+// once per CU instead of twice.  Round 4's stamps had the waves of a SIMD waiting at their barriers 28 % of the time; halving the
+// barriers and sharing the ring changed NOTHING (same-box A/B, profiles/r05_egnn_variants_ab.log) -- the wait is not the barrier's.
+// The default stays round 4's form: two workgroups of four waves per CU, a ring of three slots each, a barrier per block.
+constexpr bool EGNN_W8 = MS_EGNN_W8 != 0;
+constexpr int EDGE_RING_SPLIT = EGNN_W8 ? 6 : 3;
+constexpr int EDGE_LDS_SPLIT = EDGE_RING_SPLIT * W2S_BLOCK_BYTES; // split form: slots of one k block (24 KiB) each: 144 KiB (72 KiB with 3)
 
 // SPLIT (round 4): the same GEMM on the bf16 matrix instruction -- v_mfma_f32_32x32x16_bf16 at 16 x the rate of the fp32 one --
 // with both operands split three ways (split3_pair): per 16 k and 32 channels SIX matrix instructions (hi.hi, hi.mid, mid.hi,
@@ -332,13 +350,17 @@ constexpr int EDGE_LDS_SPLIT = 3 * W2S_BLOCK_BYTES;               // split form:
 // that computes it (~45 vector instructions per 8 values, in the shadow of the 48 matrix instructions of a k block: next to the
 // bf16 matrix instruction vector instructions are NOT additive).  One barrier per k block.
 template <bool SPLIT>
-__global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
+__global__ __launch_bounds__((SPLIT && EGNN_W8) ? 512 : 256, 2) void ms_egnn_edge_kernel(const EdgeParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4 *Wring = reinterpret_cast<f32x4 *>(smem);                 // [2 slots][5 g][8 nt][64 lanes]
+    constexpr bool W8 = SPLIT && EGNN_W8;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int T = blockIdx.x;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);  // 0..7 with eight waves: DMA pieces are dealt over all of them
+    const int wave = W8 ? (wave_all & 3) : wave_all;                // this wave's 32 rows inside ITS tile
+    const int T_raw = W8 ? 2 * (int)blockIdx.x + (wave_all >> 2) : (int)blockIdx.x;
+    const bool tile_valid = T_raw < p.n_tiles;                      // (an odd number of tiles: the last workgroup's second half only loads and synchronises)
+    const int T = tile_valid ? T_raw : p.n_tiles - 1;
     const int d = find_segment(p.tile_pre, p.nb, T);
     const int off = p.offsets[d];
     const int n = p.offsets[d + 1] - off;
@@ -464,10 +486,11 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         const u32x4_e *Sring = reinterpret_cast<const u32x4_e *>(smem);      // [3 slots][8 nt][3 parts][64 lanes] of 16 bytes
         const u32x4_e *w2s = reinterpret_cast<const u32x4_e *>(p.prep + P_W2S);
         constexpr int BLK_V = 8 * 3 * 64;                                    // 16-byte vectors per k block
-        auto dma_s = [&](int b, int piece) {                                 // pieces 6 w .. 6 w + 5 (1 KiB each) of block b -> slot b % 3
-            const int pidx = wave * 6 + piece;
+        constexpr int PPW = W8 ? 3 : 6;                                      // 1 KiB pieces of a block per wave (24 in all)
+        auto dma_s = [&](int b, int piece) {                                 // pieces PPW w .. PPW w + PPW - 1 of block b -> slot b % ring
+            const int pidx = wave_all * PPW + piece;
             const uint64_t base = (uint64_t)(uintptr_t)w2s + ((uint64_t)b * BLK_V + (uint64_t)pidx * 64) * 16;
-            const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((b % 3) * BLK_V + pidx * 64) * 16));
+            const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(((b % EDGE_RING_SPLIT) * BLK_V + pidx * 64) * 16));
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(dst), "v"(voff_w), "s"(base) : "memory", "m0");
         };
         // lane (r, h) owns edge row 32 w + r and the k half h of every block: k = 16 b + 8 h + j = quads 4 b + 2 h, 4 b + 2 h + 1.
@@ -503,10 +526,12 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
             }
             ah = __builtin_bit_cast(bf16x8_e, hi); am = __builtin_bit_cast(bf16x8_e, mid); al = __builtin_bit_cast(bf16x8_e, lo);
         };
+        // prologue: the first blocks of the ring are requested before anything else (8 waves: four blocks ahead; 4 waves: two)
+        constexpr int AHEAD = W8 ? 4 : 2;
 #pragma unroll
-        for (int pc_ = 0; pc_ < 6; ++pc_) dma_s(0, pc_);
+        for (int b0 = 0; b0 < AHEAD; ++b0)
 #pragma unroll
-        for (int pc_ = 0; pc_ < 6; ++pc_) dma_s(1, pc_);
+            for (int pc_ = 0; pc_ < PPW; ++pc_) dma_s(b0, pc_);
         load6(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         bf16x8_e ah, am, al, nh, nm, nl;
@@ -515,14 +540,31 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         load6(1);
         for (int b = 0; b < KB16; ++b) {
             // W2S block b has landed for every wave (each waited for its own pieces in the middle of the last iteration), and every
-            // wave is done reading slot (b - 1) % 3, which block b + 2 is about to overwrite
-            __syncthreads();
+            // wave is done reading slot (b - 1) % 3, which block b + 2 is about to overwrite.
+            // Eight waves, six slots: ONE barrier per PAIR of blocks -- before blocks 2p, 2p + 1 every wave has waited for its pieces of
+            // both (they were requested four blocks ahead; the vmcnt(0) in the middle of block 2p - 1 covers everything requested up to
+            // block 2p - 2, i.e. blocks <= 2p + 2) and is done with the pair before; during block b the pieces of block b + 4 go to
+            // slot (b + 4) % 6 = (b - 2) % 6, a slot of the PREVIOUS pair, which nobody reads any more.
+            if (!W8 || (b & 1) == 0) __syncthreads();
             EST(tB1)
-            const u32x4_e *Sl = Sring + (b % 3) * BLK_V + lane;
+            const u32x4_e *Sl = Sring + (b % EDGE_RING_SPLIT) * BLK_V + lane;
+            // (round 5: the three B fragments of channel tile nt + 1 are requested BEFORE the six matrix instructions of tile nt -- hipcc
+            //  left every ds_read_b128 right in front of its first use with an s_waitcnt behind it: eight exposed LDS round trips per
+            //  block and wave; MS_EGNN_BPREFETCH=0 at build time keeps that form)
+            u32x4_e bq[3] = {Sl[0], Sl[64], Sl[128]};
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
+#if MS_EGNN_BPREFETCH
+                const u32x4_e c0 = bq[0], c1 = bq[1], c2 = bq[2];
+                if (nt + 1 < 8) {
+                    bq[0] = Sl[((nt + 1) * 3 + 0) * 64]; bq[1] = Sl[((nt + 1) * 3 + 1) * 64]; bq[2] = Sl[((nt + 1) * 3 + 2) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8_e bh = __builtin_bit_cast(bf16x8_e, c0), bm = __builtin_bit_cast(bf16x8_e, c1), bl = __builtin_bit_cast(bf16x8_e, c2);
+#else
                 const bf16x8_e bh = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 0) * 64]), bm = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 1) * 64]),
                                bl = __builtin_bit_cast(bf16x8_e, Sl[(nt * 3 + 2) * 64]);
+#endif
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[nt], 0, 0, 0);
@@ -535,8 +577,12 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     make_a(nh, nm, nl);
                 }
-                if (nt >= 5 && b + 2 < KB16) { dma_s(b + 2, 2 * (nt - 5)); dma_s(b + 2, 2 * (nt - 5) + 1); }
-                if (nt == 7 && b + 2 < KB16) load6(b + 2);
+                if constexpr (W8) {
+                    if (nt >= 5 && b + 4 < KB16) dma_s(b + 4, nt - 5);
+                } else {
+                    if (nt >= 5 && b + 2 < KB16) { dma_s(b + 2, 2 * (nt - 5)); dma_s(b + 2, 2 * (nt - 5) + 1); }
+                }
+                if (nt == MS_EGNN_LOAD_NT && b + 2 < KB16) load6(b + 2);
             }
             EST(tM)
             ah = nh; am = nm; al = nl;
@@ -593,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
 
     // per-residue partial sums over this wave's 32 consecutive edges (m_i = sum_j m_ij, :69)
     const int64_t u0 = e0 + 32 * wave;                 // first edge of the unit
-    if (u0 < nn) {
+    if (tile_valid && u0 < nn) {
         const int unit = tt * 4 + wave;                // 32-edge unit index inside the structure
         const int C = (n + 31) / 32 + 1;
         const int i_first = (int)(u0 / n);
@@ -627,7 +673,7 @@ __global__ __launch_bounds__(256, 2) void ms_egnn_edge_kernel(const EdgeParams p
         }
     }
 #ifdef MS_STAMP
-    if (tid == 0 && p.stamps != nullptr && T < 32768) {
+    if ((tid & 255) == 0 && tile_valid && p.stamps != nullptr && T < 32768) {
         unsigned long long *o = p.stamps + 8 * (size_t)T;
         o[0] = tH; o[1] = tB1; o[2] = tM; o[3] = tB2; o[4] = __builtin_amdgcn_s_memtime() - t_loop_end; o[5] = 1; o[6] = t_begin;
     }
@@ -882,11 +928,12 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
         MS_LAUNCH_CHECK("ms_egnn_proj_kernel");
         EdgeParams ep;
         ep.prep = lp; ep.coords = coords; ep.offsets = offsets; ep.tile_pre = tile_pre; ep.rec_pre = rec_pre;
-        ep.ApT4 = ap; ep.BpT4 = bp; ep.part = part; ep.nb = nb; ep.total = (int)total;
+        ep.ApT4 = ap; ep.BpT4 = bp; ep.part = part; ep.nb = nb; ep.total = (int)total; ep.n_tiles = (int)tiles;
 #ifdef MS_STAMP
         ep.stamps = ms_egnn_stamp_buffer();
 #endif
-        if (split_form) hipLaunchKernelGGL(ms_egnn_edge_kernel<true>, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
+        if (split_form && EGNN_W8) hipLaunchKernelGGL(ms_egnn_edge_kernel<true>, dim3((unsigned)((tiles + 1) / 2)), dim3(512), edge_lds, st, ep);
+        else if (split_form) hipLaunchKernelGGL(ms_egnn_edge_kernel<true>, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
         else hipLaunchKernelGGL(ms_egnn_edge_kernel<false>, dim3((unsigned)tiles), dim3(256), edge_lds, st, ep);
         MS_LAUNCH_CHECK("ms_egnn_edge_kernel");
         NodeParams np;

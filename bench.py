@@ -338,7 +338,11 @@ class SearchBench:
         kk = min(k + 4, max(self.n_local, 1))
         qn = self.q_raw[:nb] / self.q_raw[:nb].norm(dim=1, keepdim=True)
         bs = bi = None
-        chunk = max(1, min(self.n_local, (1 << 31) // max(nb, 1)))
+        # (row chunks of at most 2^20: with 2^31 / nb rows per chunk -- a [64, 2^25] score matrix, 2^31 elements, in one matmul + topk --
+        #  torch's brute force itself came out wrong at the C4 shard (recall 0.92 "against" it, 48 of 64 lists; 32-bit indexing or the
+        #  library GEMM at that size: not investigated), while the same product in 2^19..2^20-row chunks agrees with the scan to 2e-6 for
+        #  all 4096 queries (tests/test_fullsize_gpu.py) and gives 64 of 64 identical lists here)
+        chunk = max(1, min(self.n_local, 1 << 20, (1 << 31) // max(nb, 1)))
         for r0 in range(0, self.n_local, chunk):
             top = torch.topk(qn @ self.db[r0:r0 + chunk].T, min(kk, self.n_local - r0), dim=1)
             idx = top.indices + (r0 + self.lo)

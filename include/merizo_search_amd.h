@@ -177,7 +177,7 @@ int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int pf_
  * how many of its queries needed the exact pass (0: every answer was proved), *gate_value == *last_epoch iff any did. */
 int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned int *last_epoch, unsigned int *flagged);
 /* Diagnostics (tools/pf_debug.py): the candidate lists of the last prefiltered search on this workspace, copied to the host
- * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); image: was it a search over a split image; -1 when the shape is
+ * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); image: 0 = no image, 1 = the split-bf16 image, 2 = the fp16 image; -1 when the shape is
  * not served by the prefilter. */
 int ms_debug_prefilter_lists(void *workspace, int64_t n, int nq, int k, int image, float *as_host, int64_t *ai_host, int *kp_out);
 

@@ -156,7 +156,7 @@ def knn_exact(xq, db_blocks, k: int, engine, log=logger, row_offset: int = 0, to
         ni = block.shape[0]
         if ni == 0:
             continue
-        # (a resident shard comes with its row-norm bound and, memory permitting, its split image: large batches then take the
+        # (a resident shard comes with its row-norm bound and, memory permitting, its fp16 image (built on first use): large batches -- and, from 1M rows, any batch -- then take the
         #  prefiltered search -- same results)
         s, i = (engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries, row_norm_bound=row_norm_bound, pf_image=pf_image)
                 if row_norm_bound is not None else engine.ip_topk(block, q, k, row_offset=i0, normalize_queries=raw_queries))

@@ -15,7 +15,7 @@ Engine interface (tensors are torch tensors on the engine's device):
     cosine_topk(rows, q, k, lengths, qlen, mincov, row_offset[, pf_image]) -> (scores [nq,k], idx int64 [nq,k])
     ip_topk(db, q, k, row_offset, normalize_queries[, row_norm_bound, pf_image]) -> (scores [nq,k], idx int64 [nq,k]);
                                                                normalize_queries: q raw, F.normalize (eps 1e-12) fused into the call
-    pf_image(db)                                            -> the split-bf16 image of a resident matrix for the prefiltered search
+    pf_image(db) / lazy_pf_image(db)                        -> the fp16 image of a resident matrix for the prefiltered search (built on first use)
                                                                (None when HBM has no room for it), built once per database
     topk_merge(scores [S,nq,k], idx [S,nq,k])               -> (scores [nq,k], idx [nq,k])
     merge_gathered(PackedExchange)                          -> (scores [nq,k], idx [nq,k])  multi-rank merge
@@ -156,8 +156,8 @@ class HipEngine:
     def ip_topk(self, db, q, k, row_offset: int = 0, normalize_queries: bool = False, row_norm_bound=None, pf_image=None):
         """index.search of dbsearch.py:234-242.  row_norm_bound: an upper bound on the rows' L2 norms when the caller knows one
         (`row_norm_bound(db)` once per resident database): batches of more than 64 queries then take the prefiltered search
-        (ms_ip_topk_prefiltered: same results bit for bit; the rows scanned with bf16 matrix instructions -- over `pf_image`, the
-        split image built when the database became resident, or split in registers without one).  Queries whose answer the
+        (ms_ip_topk_prefiltered: same results bit for bit; the rows scanned with fp16 matrix instructions over `pf_image`, the fp16
+        image of the resident database -- any number of queries from 1M rows on -- or split in registers without one).  Queries whose answer the
         prefilter cannot prove get an exact pass of their own inside the same call: no feedback loop, no switch."""
         ops = self._ops
         mode = ops.MODE_IP_NORMQ if normalize_queries else ops.MODE_IP_PRENORM

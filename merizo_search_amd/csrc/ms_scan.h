@@ -69,6 +69,8 @@ struct ScanParams {
                                              // over the flagged queries of a prefiltered search); workgroups past its grid return at once
     const void *pf_image = nullptr;   // prefilter, ms_scan_pf.h / ms_scan_pf16.h: the image of db (ms_pf_build_image), or NULL (split in registers)
     int pf_format = 0;                // ... and its arithmetic: MS_PF_BF16X3 (32-row tiles), MS_PF_F16X2 / MS_PF_F16X1 (64-row tiles)
+    int list_sm = 0;                  // the launch writes its per-stream lists STREAM-MAJOR ([stream][query][rank]: a workgroup's lists are one contiguous block;
+                                      // the image scans always, the loader-wave kernel when its merge can read them: ScanPlan::list_sm) instead of rank-major
     uint32_t *prog = nullptr;         // fp16-image scan with 2..16 query groups per row stream: [n_streams][16] progress words (epoch << 16 | tile),
     uint32_t prog_epoch = 0;          // by which the workgroups of a stream keep within one L2 window of each other (ms_scan_pf16.h); NULL: off
     int qpw = 1;                      // ... and the waves per workgroup of that kernel, one query tile each, in fours (1: 4 waves, 2: 8)
@@ -1810,12 +1812,13 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
         const float other = ms_xor32_f(smax, h);
         if (h == 0) {
             const float hi = (other > smax) ? other : smax, lo = (other > smax) ? smax : other;
-            const size_t o = ((size_t)qidx * p.k + 0) * p.P + stream;
+            const size_t o = p.list_sm ? ((size_t)stream * p.nq_pad + qidx) * p.k : ((size_t)qidx * p.k + 0) * p.P + stream;
+            const size_t o1 = p.list_sm ? o + 1 : o + p.P;
             p.part_s[o] = hi;
             p.part_i[o] = (hi > -INFINITY) ? (uint32_t)(2 * stream) : MS_IDX_NONE;
             if (p.k > 1) {
-                p.part_s[o + p.P] = lo;
-                p.part_i[o + p.P] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
+                p.part_s[o1] = lo;
+                p.part_i[o1] = (lo > -INFINITY) ? (uint32_t)(2 * stream + 1) : MS_IDX_NONE;
             }
         }
         return;
@@ -1824,7 +1827,10 @@ __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams
     for (int j = 0; j < (SAMPLE ? 1 : KL); ++j) {
         const int rank = h * KL + j;
         if (rank < p.k) {
-            const size_t o = ((size_t)qidx * p.k + rank) * p.P + stream;
+            // (stream-major when the merge behind this launch reads it: a workgroup's lists are then one contiguous block that the L2
+            //  writes back as whole lines -- rank-major, every 4-byte entry shares its line with the other streams' workgroups on other
+            //  XCDs: 26.5 MB of HBM writes for a 2.6 MB payload at C2; ms_scan_pf16.h)
+            const size_t o = p.list_sm ? ((size_t)stream * p.nq_pad + qidx) * p.k + rank : ((size_t)qidx * p.k + rank) * p.P + stream;
             p.part_s[o] = st.ls[j];
             p.part_i[o] = st.li[j];
         }
@@ -1846,6 +1852,7 @@ struct ScanPlan {
     int grid;
     int prepass_tiles;     // tiles per stream scanned by the sample pass (0 = no sample pass)
     int qpw;               // split-image prefilter scan (ms_scan_pf.h): query tiles per wave (0: any other kernel)
+    int list_sm;           // the scan of this plan writes stream-major lists (the image scans; the loader-wave kernel when P <= 256 and the block merge takes them)
     size_t lds_bytes;
     // workspace carve (byte offsets)
     size_t off_qn, off_inv, off_part_s, off_part_i, off_ub_s, off_ub_i, off_lb_s, off_lb_i, off_scr_s, off_scr_i, off_hist, off_hstep, off_prog, total;

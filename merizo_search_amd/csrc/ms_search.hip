@@ -795,6 +795,13 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
         pl.grid = ((pl.n_sgroups + 7) / 8) * 8 * pl.n_qgroups;
     }
     pl.lds_bytes = 4 * 32768 + 4 * 1024;        // tile slots, cosine side data, in-launch bound
+    // stream-major lists: the image scans always; the loader-wave kernel (>= 3 query tiles, one pass) when the workgroup-per-query merge
+    // reads them (<= 256 lists whose [k][P] staging fits the LDS) -- MS_LIST_SM=0: rank-major as in rounds 1-4
+    {
+        static const int sm_setting = [] { const char *e = getenv("MS_LIST_SM"); return e ? atoi(e) : 1; }();
+        const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)pl.k_pass * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
+        pl.list_sm = (qpw > 0 || (sm_setting && pl.qwb == 4 && loader_wave_setting() && k <= 64 && pl.P <= 256 && block_lds <= 156 * 1024)) ? 1 : 0;
+    }
     // sample pass: the k-th best score of the first few tiles of every stream bounds the answer
     // from below and prunes almost every insertion of the full pass; worth it for long streams
     // Size of the sample: T0 tiles per stream cost T0 tile times; the insertion steps they save in the
@@ -962,6 +969,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->hist = nullptr; sp->hstep = nullptr;
     sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
     sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0; sp->pf_image = nullptr; sp->pf_format = 0; sp->qpw = pl.qpw;
+    sp->list_sm = pl.list_sm; sp->prog = nullptr; sp->prog_epoch = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp->part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
     sp->rows_per_stream = pl.rows_per_stream; sp->n_streams = pl.n_streams; sp->n_qtiles = pl.n_qtiles;
@@ -994,7 +1002,7 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
         if (ranks > cap) ranks = cap > 1 ? cap : 1;
     }
     const int vpl = (ranks * pl.P + 63) / 64;
-    const size_t sm_stride = (s0.prefilter && s0.pf_image != nullptr) ? (size_t)pl.nq_pad * s0.k : 0;       // (the image scans write stream-major lists)
+    const size_t sm_stride = s0.list_sm ? (size_t)pl.nq_pad * s0.k : 0;       // (the image scans, and the loader-wave kernel where its merge allows, write stream-major lists)
     if (vpl > 32 && sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: %d sample lists of the image scan exceed the bound selection", pl.P);
     if (vpl <= 32) {
         const bool hist_on = pl.qwb == 4 && loader_wave_setting() && hist_setting();
@@ -1154,7 +1162,8 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
     ScanParams sp;
     sp.part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
     sp.part_i = reinterpret_cast<uint32_t *>(ws + pl.off_part_i);
-    return launch_merge(pl, sp, nq, pl.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, (hipStream_t)stream);
+    return launch_merge(pl, sp, nq, pl.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, (hipStream_t)stream, nullptr, nullptr, 0,
+                        pl.list_sm ? (size_t)pl.nq_pad * pl.k_pass : 0);
 }
 
 int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, int nq, int k, int mode,
@@ -1195,7 +1204,7 @@ int ms_ip_topk(const float *db, int64_t n, int64_t row_offset, const float *q, i
         if (rc) return rc;
         const bool more = col0 + 64 < k;
         rc = launch_merge(pl, sp, nq, kp, row_offset, out_scores, out_idx, k, col0, more ? ub_s : nullptr,
-                          more ? ub_i : nullptr, st);
+                          more ? ub_i : nullptr, st, nullptr, nullptr, 0, sp.list_sm ? (size_t)pl.nq_pad * kp : 0);
         if (rc) return rc;
         sp.ub_s = ub_s;
         sp.ub_i = ub_i;
@@ -1363,7 +1372,7 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         if (block_lds > 48 * 1024)
             MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_merge_rescore_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)block_lds));
         hipLaunchKernelGGL(ms_merge_rescore_kernel, dim3(nq), dim3(256), block_lds, st, sp.part_s, sp.part_i, pl.P, as, ai,
-                           image != nullptr ? (size_t)pl.nq_pad * L.kp : (size_t)0, ra);
+                           sp.list_sm ? (size_t)pl.nq_pad * L.kp : (size_t)0, ra);
         MS_LAUNCH_CHECK("ms_merge_rescore_kernel");
         // The exact pass, for the flagged queries ONLY (the reference's semantics are per query: dbsearch.py:234-242): an fp32 scan
         // and a merge over the compacted batch, decomposed on the device (ScanDevPlan), both returning at once when no query was
@@ -1382,6 +1391,7 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         ScanPlan pg = px;
         pg.grid = L.exact_grid_max; pg.P = L.exact_P_max; pg.qwb = 1;     // (qwb = 1: routes to ms_scan_kernel, whose decomposition is the device plan's)
         sx.qwb = 1;
+        sx.list_sm = 0;                      // (ms_scan_kernel writes rank-major lists)
         rc = launch_scan(pg, sx, st);
         if (rc) return rc;
         rc = launch_merge(pg, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st, dp, qmap);

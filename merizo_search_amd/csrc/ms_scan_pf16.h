@@ -319,6 +319,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     //      optimisation, never a condition for progress).  The other waves of the workgroup follow through the arrival counters.
     const bool pace_on = !SAMPLE && p.prog != nullptr;          // (uniform)
     constexpr int PACE_LEAD = 48;
+    int pace_left = 16384;          // sleeps of ~2 us this workgroup may spend waiting in all (32 ms): should the workgroups of a stream NOT be
+                                    // co-resident (fewer CUs than the plan assumed), the leaders give up pacing instead of waiting for a
+                                    // workgroup that has not started
     auto pace = [&](int t) __attribute__((always_inline)) {
         if (wave != 0 || (t & 15) != 0) return;
         const uint64_t line = (uint64_t)(uintptr_t)(p.prog + (size_t)stream * 16);
@@ -328,7 +331,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         if (lane == 0) __hip_atomic_store(p.prog + (size_t)stream * 16 + qg, tag | (uint32_t)t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < PACE_LEAD) return;
         typedef uint32_t u32x16_ __attribute__((ext_vector_type(16)));
-        for (uint32_t spins = 0; spins < 4096u; ++spins) {
+        for (; pace_left > 0; --pace_left) {
             u32x16_ w;
             asm volatile("s_load_dwordx16 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(w) : "s"(sline) : "memory");
             uint32_t mn = 0xFFFFFFu;

@@ -651,6 +651,9 @@ int64_t pf_few_min_rows() {         // <= 64 queries take the fp16-image scan fr
     return v;
 }
 
+#ifndef MS_PF_SAMPLE_COEF_DEFAULT
+#define MS_PF_SAMPLE_COEF_DEFAULT 0.3        // the constant of the sample-size rule for the image scans (MS_PF_SAMPLE_COEF overrides)
+#endif
 int sample_min_queries_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_SAMPLE_MIN_NQ"); v = e ? atoi(e) : 8; }
@@ -815,7 +818,8 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
     //  k-th best scores are too close for the histogram to have buckets: the old rule)
     pl.prepass_tiles = prepass_tiles_setting();
     if (pl.prepass_tiles < 0) {
-        const double c = (qpw == 0 && pl.qwb == 4 && pl.k_pass >= 5 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : 0.3;      // (the split-image
+        static const double pf_coef = [] { const char *e = getenv("MS_PF_SAMPLE_COEF"); return e ? atof(e) : MS_PF_SAMPLE_COEF_DEFAULT; }();
+        const double c = (qpw == 0 && pl.qwb == 4 && pl.k_pass >= 5 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : (qpw > 0 ? pf_coef : 0.3);      // (the split-image
                                      // scan only appends between flushes: its thresholds move with the shared bound alone, and it wants the larger sample)
         const double t0 = sqrt(c * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
         pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));

@@ -652,7 +652,10 @@ int64_t pf_few_min_rows() {         // <= 64 queries take the fp16-image scan fr
 }
 
 #ifndef MS_PF_SAMPLE_COEF_DEFAULT
-#define MS_PF_SAMPLE_COEF_DEFAULT 0.3        // the constant of the sample-size rule for the image scans (MS_PF_SAMPLE_COEF overrides)
+#define MS_PF_SAMPLE_COEF_DEFAULT 1.2        // the constant of the sample-size rule for the image scans with more than 64 queries (MS_PF_SAMPLE_COEF
+                                             // overrides): twice the sample of the fp32 rule's 0.3 -- a visit of the rare path costs these kernels ~900 cycles per
+                                             // half tile and a sample tile next to nothing (the sample launch is mostly fixed cost): C2 0.145 -> 0.137 ms per
+                                             // call, every other shape within 1 % (profiles/r05_pf_sample_coef_sweep.log); few-query plans keep 0.3
 #endif
 int sample_min_queries_setting() {
     static int v = -1;
@@ -819,7 +822,7 @@ ScanPlan make_plan(int64_t n, int nq, int k, int cus, int qpw = 0, int tile_rows
     pl.prepass_tiles = prepass_tiles_setting();
     if (pl.prepass_tiles < 0) {
         static const double pf_coef = [] { const char *e = getenv("MS_PF_SAMPLE_COEF"); return e ? atof(e) : MS_PF_SAMPLE_COEF_DEFAULT; }();
-        const double c = (qpw == 0 && pl.qwb == 4 && pl.k_pass >= 5 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : (qpw > 0 ? pf_coef : 0.3);      // (the split-image
+        const double c = (qpw == 0 && pl.qwb == 4 && pl.k_pass >= 5 && loader_wave_setting() && hist_setting()) ? sample_coef_setting() : (qpw > 0 && nq > 64 ? pf_coef : 0.3);      // (the split-image
                                      // scan only appends between flushes: its thresholds move with the shared bound alone, and it wants the larger sample)
         const double t0 = sqrt(c * (double)tiles_per_stream * ((double)pl.k_pass / 10.0) * (128.0 / (double)pl.n_streams));
         pl.prepass_tiles = t0 < 1.0 ? 1 : (t0 > 32.0 ? 32 : (int)(t0 + 0.5));

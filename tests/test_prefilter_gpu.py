@@ -435,7 +435,7 @@ def test_the_arithmetic_is_chosen_per_database_by_searching_its_own_rows(torch_g
 
 
 @pytest.mark.parametrize("image", ["f16x2", "f16x1"])
-@pytest.mark.parametrize("nq,k", [(1, 10), (3, 1), (17, 10), (32, 20), (33, 5), (64, 10)])
+@pytest.mark.parametrize("nq,k", [(1, 10), (3, 1), (17, 10), (32, 20), (33, 5), (64, 10), (5, 40), (2, 48)])
 def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, torch_gpu):
     """The reference's own CLI regime (one to a few query domains per call, dbsearch.py:531-546) is HBM-bound: from ms_pf_few_min_rows()
     rows on, ms_ip_topk_prefiltered serves ANY number of queries over an fp16 image -- 256 B per row instead of 512.  2.1M rows (the

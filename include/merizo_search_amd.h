@@ -9,6 +9,9 @@
  * synchronise.  Return 0 on success, a negative MS_ERR_* otherwise; ms_last_error() gives
  * the message of the calling thread's last failure.  Embedding width is fixed at 128
  * (FoldClassNet(128), reference programs/Foldclass/dbsearch.py:40).
+ * Threading: entry points may be called from any host thread; a WORKSPACE serves one stream at a time (calls that share a workspace
+ * must be ordered on one stream: the searches keep lists, counters and the exact pass's launch plan in it between their launches) --
+ * concurrent searches take one workspace each.
  *
  * Paths below are relative to /root/reference/merizo_search/programs/Foldclass/.
  */

@@ -489,3 +489,21 @@ def test_few_queries_cosine_with_length_mask_over_the_fp16_image(nq, torch_gpu):
     for image in (img, img.as_format(ops.PF_F16X1)):
         s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, row_offset=3, workspace=ws, image=image, **kw)
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+
+
+@pytest.mark.parametrize("image", ["f16x2", "f16x1"])
+@pytest.mark.parametrize("nq,owners", [(1, [0]), (3, [1]), (20, [0, 7, 19]), (64, [5, 63])])
+def test_few_queries_whose_proof_fails_get_the_exact_pass_too(nq, owners, image, torch_gpu):
+    """The few-query plan of the image scan (one workgroup row per CU, <= 2 query tiles) with queries that own a family of 200
+    near-duplicates: those are flagged, compacted and scanned exactly (ms_scan_kernel on the device plan for 1 .. 3 queries), the
+    others keep the proved answer; all == the oracle."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, k = 1_050_000, 10
+    db, q = _norm_db(n, seed=591), _norm_db(nq, seed=592 + nq)
+    rng = np.random.default_rng(12)
+    rows = rng.choice(n, size=(len(owners), 200), replace=False)
+    for j, qi in enumerate(owners):
+        db[rows[j]] = _family(rng, q[qi], 200)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=17, expect_flagged=len(owners), image=image)

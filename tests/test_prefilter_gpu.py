@@ -480,6 +480,7 @@ def test_few_queries_cosine_with_length_mask_over_the_fp16_image(nq, torch_gpu):
     from merizo_search_amd import ops
     n, k = 1_050_000, 10
     db, q, lengths, qlen = _cosine_case(n, nq, seed=580 + nq)
+    qlen[nq - 1] = 1.0                      # shorter than every row * mincov: everything masked for the last query (all scores +-0: no proof, exact pass)
     d, dq, dl, dql = _dev(torch, db), _dev(torch, q), _dev(torch, lengths), _dev(torch, qlen)
     unit = ops.l2_normalize_rows_(d.clone(), 1e-8)
     kw = dict(mode=ops.MODE_COSINE_UNIT, lengths=dl, qlen=dql, mincov=0.7)
@@ -489,6 +490,7 @@ def test_few_queries_cosine_with_length_mask_over_the_fp16_image(nq, torch_gpu):
     for image in (img, img.as_format(ops.PF_F16X1)):
         s1, i1 = ops.ip_topk_prefiltered(unit, dq, k, 1.0 + 1e-5, row_offset=3, workspace=ws, image=image, **kw)
         assert torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+        assert ops.prefilter_flagged(ws) >= 1
 
 
 @pytest.mark.parametrize("image", ["f16x2", "f16x1"])

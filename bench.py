@@ -32,8 +32,10 @@ goes to bench_full.json beside this file and to stderr.  The blocks:
                 tiles): algorithmic flops (2*128*nq*rows per launch) over the HIP-event duration of the launch against the fp32
                 MFMA peak (157.3 TFLOP/s) when nq >= 39, else algorithmic bytes (512 B per row) against the 8 TB/s HBM peak; both
                 fractions always included, plus `step_frac`: the same work over the whole step time (what the user gets);
-                `traffic` (HBM bytes per launch) is NOT measured by this run -- counters need the profiler -- but copied from the
-                PMC passes of the same workload committed under profiles/: `traffic_from_committed_profile` / `traffic_source`;
+                `traffic` (HBM bytes per launch) of the TOP-LEVEL kernel is measured by this run itself: after the timed regions two
+                `rocprofv3 --kernel-trace --pmc` child passes (FETCH_SIZE; WRITE_SIZE) of this script on the same workload, gfx950
+                corrections applied (`--no-live-traffic`, or no rocprofv3: the figure of the committed PMC passes under profiles/, and
+                `traffic_from` says which); the other blocks carry the committed profiles' figures (`traffic_source`);
   prefiltered   (N = 1) the same step through the prefiltered search: ms per step, q/s, identical_to_fp32, how many queries needed
                 the exact pass, and the roofs of ITS scan launch (ms_scan_pf2_kernel): the algorithmic flops UN-tripled, the
                 flops it executes (3 bf16 matrix instructions per 16 dimensions) against the dense bf16 matrix peak, the bytes of
@@ -161,6 +163,52 @@ def attach_committed_traffic(roof, pmc_name):
     roof["traffic_from"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload)" % pmc_name
     if pmc.get("matrix_pipe_busy_fraction") is not None:
         roof["matrix_pipe_busy_fraction_from_committed_profile"] = pmc["matrix_pipe_busy_fraction"]
+
+
+def measure_traffic_live(kernel, log, timeout_s=150):
+    """HBM bytes per launch of the top-level step's scan kernel, measured NOW: two `rocprofv3 --kernel-trace --pmc <counter>` CHILD passes
+    (FETCH_SIZE; WRITE_SIZE: counters that cannot share a pass) of this very script on the same workload (`--no-extras --no-cpu-baseline
+    --no-prefilter --steps 5 --warmup 3`), corrected as MI355X_MICROARCH.md prescribes (KiB units; gfx950 reports half of a wide /
+    LDS-DMA read stream: reads = 2 x FETCH_SIZE x 1024).  The children are started as fresh processes (nothing is exec'd in this one) under
+    a hard time limit and killed as a group past it.  -> (bytes per launch, launches counted) or None (no rocprofv3, a pass failed or
+    timed out: the caller keeps the figure of the committed profile and says so)."""
+    import csv
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    means, counted = {}, 0
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="ms_pmc_")
+        cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", os.path.realpath(sys.executable), os.path.abspath(__file__),
+               "--no-extras", "--no-cpu-baseline", "--no-prefilter", "--no-live-traffic", "--steps", "5", "--warmup", "3"]
+        env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        env["TMPDIR"] = tempfile.gettempdir()
+        proc = subprocess.Popen(cmd, cwd=tempfile.gettempdir(), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)
+            except ProcessLookupError:
+                pass
+            proc.wait()
+            rc = -9
+        vals = []
+        if rc == 0:
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    vals += [float(r["Counter_Value"]) for r in csv.DictReader(fh) if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+        shutil.rmtree(d, ignore_errors=True)
+        if not vals:
+            log("live traffic: the %s pass gave nothing (rc %s): keeping the committed profile's figure" % (ctr, rc))
+            return None
+        means[ctr], counted = float(np.mean(vals)), len(vals)
+    return 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0, counted
 
 
 class SearchBench:
@@ -763,6 +811,9 @@ def main():
                          "step -- the like-for-like first point of the weak-scaling curve that --gpus N>1 measures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip hbm_regime / c4_shard / embed")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not measure roofline.traffic with rocprofv3 child passes (N = 1, default C2 shape, extras on: two passes of ~25 s); the "
+                         "figure of the committed profile is used instead")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the `prefiltered` blocks (the top-level line is the fp32 scan either way)")
     ap.add_argument("--exercise-exchange", action="store_true",
                     help="run the multi-GPU exchange + shard merge even on one GPU (validates that code path; slower)")
@@ -1019,6 +1070,16 @@ def main():
         del c3_state, enc
         bench.db, bench.q_raw = db_keep, q_keep
 
+    if rank == 0 and world == 1 and c2 and not args.no_live_traffic and (not args.no_extras or os.environ.get("MS_BENCH_LIVE_TRAFFIC") == "1"):
+        # roofline.traffic of the top-level kernel, measured in THIS run (the GPU is idle now: every timed region is over)
+        live = measure_traffic_live("ms_scan_loader_kernel<5, 0, false, false>", log)
+        if live is not None:
+            line["roofline"]["traffic_committed_profile"] = line["roofline"].get("traffic")
+            line["roofline"]["traffic"] = live[0]
+            line["roofline"]["traffic_from_committed_profile"] = False
+            line["roofline"]["traffic_from"] = "measured in this run (2 rocprofv3 --pmc child passes, %d launches)" % live[1]
+            line["roofline"]["traffic_source"] = line["roofline"]["traffic_from"]
+            log("live traffic of the top-level scan launch: %.1f MB = %.3f x the algorithmic bytes" % (live[0] / 1e6, live[0] / line["roofline"]["algorithmic_bytes_per_launch"]))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             q_unit = bench.q_raw / bench.q_raw.norm(dim=1, keepdim=True)

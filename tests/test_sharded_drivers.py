@@ -361,3 +361,19 @@ def test_bench_shape_c4_is_the_one_rank_point_of_the_weak_scaling_curve(tmp_path
     line = _bench_line(r.stdout)
     assert line["config"]["workload"].startswith("C4 shape, ONE rank") and line["config"]["queries_per_step"] == 4096
     assert line["config"]["db_rows"] == 2_000_000 and line["recall_at_k"] == 1.0 and line["prefiltered"]["identical_to_fp32"] is True
+
+
+@pytest.mark.gpu
+def test_bench_measures_the_top_level_traffic_itself(tmp_path):
+    """`roofline.traffic` of the top-level line comes from rocprofv3 --pmc CHILD passes started by bench.py itself (FETCH_SIZE;
+    WRITE_SIZE; gfx950 corrections), not from a committed file: about the algorithmic 512 MB at C2, and the line says where it came from."""
+    import shutil
+    if shutil.which("rocprofv3") is None and not os.path.exists("/opt/rocm/bin/rocprofv3"):
+        pytest.skip("no rocprofv3 on this box")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["MS_BENCH_LIVE_TRAFFIC"] = "1"
+    r = _run_bench(["--steps", "10", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--no-prefilter"], env, 600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = _bench_line(r.stdout)
+    assert line["roofline"]["traffic_from"].startswith("measured in this run"), line["roofline"]
+    assert 0.98 * 512e6 <= line["roofline"]["traffic"] <= 1.15 * 512e6

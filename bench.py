@@ -165,13 +165,14 @@ def attach_committed_traffic(roof, pmc_name):
         roof["matrix_pipe_busy_fraction_from_committed_profile"] = pmc["matrix_pipe_busy_fraction"]
 
 
-def measure_traffic_live(kernel, log, timeout_s=150):
+def measure_traffic_live(kernels, log, timeout_s=150):
     """HBM bytes per launch of the top-level step's scan kernel, measured NOW: two `rocprofv3 --kernel-trace --pmc <counter>` CHILD passes
     (FETCH_SIZE; WRITE_SIZE: counters that cannot share a pass) of this very script on the same workload (`--no-extras --no-cpu-baseline
     --no-prefilter --steps 5 --warmup 3`), corrected as MI355X_MICROARCH.md prescribes (KiB units; gfx950 reports half of a wide /
     LDS-DMA read stream: reads = 2 x FETCH_SIZE x 1024).  The children are started as fresh processes (nothing is exec'd in this one) under
     a hard time limit and killed as a group past it.  -> (bytes per launch, launches counted) or None (no rocprofv3, a pass failed or
-    timed out: the caller keeps the figure of the committed profile and says so)."""
+    timed out: the caller keeps the figure of the committed profile and says so).  `kernels`: {key: kernel-name substring}; -> {key:
+    (bytes per launch, launches counted)} for the kernels both passes saw."""
     import csv
     import glob
     import shutil
@@ -181,11 +182,11 @@ def measure_traffic_live(kernel, log, timeout_s=150):
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
         return None
-    means, counted = {}, 0
+    means = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ms_pmc_")
         cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", os.path.realpath(sys.executable), os.path.abspath(__file__),
-               "--no-extras", "--no-cpu-baseline", "--no-prefilter", "--no-live-traffic", "--steps", "5", "--warmup", "3"]
+               "--no-extras", "--no-cpu-baseline", "--no-live-traffic", "--steps", "5", "--warmup", "3"]
         env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["TMPDIR"] = tempfile.gettempdir()
         proc = subprocess.Popen(cmd, cwd=tempfile.gettempdir(), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -198,17 +199,26 @@ def measure_traffic_live(kernel, log, timeout_s=150):
                 pass
             proc.wait()
             rc = -9
-        vals = []
+        vals = {key: [] for key in kernels}
         if rc == 0:
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 with open(f) as fh:
-                    vals += [float(r["Counter_Value"]) for r in csv.DictReader(fh) if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] != ctr:
+                            continue
+                        for key, name in kernels.items():
+                            if name in r["Kernel_Name"]:
+                                vals[key].append(float(r["Counter_Value"]))
         shutil.rmtree(d, ignore_errors=True)
-        if not vals:
-            log("live traffic: the %s pass gave nothing (rc %s): keeping the committed profile's figure" % (ctr, rc))
+        if not any(vals.values()):
+            log("live traffic: the %s pass gave nothing (rc %s): keeping the committed profiles' figures" % (ctr, rc))
             return None
-        means[ctr], counted = float(np.mean(vals)), len(vals)
-    return 2.0 * means["FETCH_SIZE"] * 1024.0 + means["WRITE_SIZE"] * 1024.0, counted
+        means[ctr] = {key: (float(np.mean(v)), len(v)) for key, v in vals.items() if v}
+    out = {}
+    for key in kernels:
+        if key in means["FETCH_SIZE"] and key in means["WRITE_SIZE"]:
+            out[key] = (2.0 * means["FETCH_SIZE"][key][0] * 1024.0 + means["WRITE_SIZE"][key][0] * 1024.0, means["FETCH_SIZE"][key][1])
+    return out or None
 
 
 class SearchBench:
@@ -1072,14 +1082,18 @@ def main():
 
     if rank == 0 and world == 1 and c2 and not args.no_live_traffic and (not args.no_extras or os.environ.get("MS_BENCH_LIVE_TRAFFIC") == "1"):
         # roofline.traffic of the top-level kernel, measured in THIS run (the GPU is idle now: every timed region is over)
-        live = measure_traffic_live("ms_scan_loader_kernel<5, 0, false, false>", log)
-        if live is not None:
-            line["roofline"]["traffic_committed_profile"] = line["roofline"].get("traffic")
-            line["roofline"]["traffic"] = live[0]
-            line["roofline"]["traffic_from_committed_profile"] = False
-            line["roofline"]["traffic_from"] = "measured in this run (2 rocprofv3 --pmc child passes, %d launches)" % live[1]
-            line["roofline"]["traffic_source"] = line["roofline"]["traffic_from"]
-            log("live traffic of the top-level scan launch: %.1f MB = %.3f x the algorithmic bytes" % (live[0] / 1e6, live[0] / line["roofline"]["algorithmic_bytes_per_launch"]))
+        # (the prefiltered step's image scan is in the same child runs: both kernels' counters from the same two passes)
+        live = measure_traffic_live({"top": "ms_scan_loader_kernel<5, 0, false, false>", "pf": "ms_scan_pf16_kernel<10, 8, false, false,"}, log)
+        targets = {"top": line["roofline"], "pf": (line.get("prefiltered") or {}).get("roofline")}
+        for key, roof_ in targets.items():
+            if live is None or key not in live or roof_ is None:
+                continue
+            roof_["traffic_committed_profile"] = roof_.get("traffic")
+            roof_["traffic"] = live[key][0]
+            roof_["traffic_from_committed_profile"] = False
+            roof_["traffic_from"] = "measured in this run (2 rocprofv3 --pmc child passes, %d launches)" % live[key][1]
+            roof_["traffic_source"] = roof_["traffic_from"]
+            log("live traffic of %s: %.1f MB = %.3f x the algorithmic bytes" % (roof_["kernel"], live[key][0] / 1e6, live[key][0] / roof_["algorithmic_bytes_per_launch"]))
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             q_unit = bench.q_raw / bench.q_raw.norm(dim=1, keepdim=True)

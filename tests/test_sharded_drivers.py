@@ -372,8 +372,10 @@ def test_bench_measures_the_top_level_traffic_itself(tmp_path):
         pytest.skip("no rocprofv3 on this box")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["MS_BENCH_LIVE_TRAFFIC"] = "1"
-    r = _run_bench(["--steps", "10", "--warmup", "3", "--no-extras", "--no-cpu-baseline", "--no-prefilter"], env, 600)
+    r = _run_bench(["--steps", "10", "--warmup", "3", "--no-extras", "--no-cpu-baseline"], env, 600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = _bench_line(r.stdout)
     assert line["roofline"]["traffic_from"].startswith("measured in this run"), line["roofline"]
     assert 0.98 * 512e6 <= line["roofline"]["traffic"] <= 1.15 * 512e6
+    pf = line["prefiltered"]["roofline"]                       # the image scan of the prefiltered step: 256 B per row
+    assert pf["traffic_from"].startswith("measured in this run") and 0.98 * 256e6 <= pf["traffic"] <= 1.2 * 256e6, pf

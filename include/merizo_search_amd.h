@@ -150,12 +150,15 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
  * ABI note: ms_version() >= 200 (round 5) -- ms_pf_image_bytes / ms_pf_build_image gained `pf_format` (+ row_norm_bound), the four
  * search entry points gained `pf_format` behind `pf_image`; version 100 callers must be rebuilt (merizo_search_amd/_lib.py checks). */
 #define MS_PREFILTER_MAX_K 48
-/* <= 64 queries (the reference's own CLI regime, dbsearch.py:531-546) are HBM-bound: over the fp16 image (MS_PF_F16X2 / F16X1) the scan
- * reads 256 B per row instead of 512, and from this many rows on that outweighs the fixed cost of the pipeline around it --
- * ms_ip_topk_prefiltered then serves ANY number of queries (below it, and over a split-bf16 image or none, <= 64 queries are
- * ms_ip_topk as before).  ms_pf_few_min_rows(): the value in force (the environment variable MS_PF_FEW_MIN_ROWS overrides). */
+/* <= 64 queries (the reference's own CLI regime, dbsearch.py:531-546) are HBM-bound up to 32 queries and two query tiles of fp32
+ * matrix work from 33: over the fp16 image (MS_PF_F16X2 / F16X1) the scan reads 256 B per row instead of 512 and multiplies in fp16,
+ * and from a row count on that outweighs the fixed cost of the pipeline around it -- ms_ip_topk_prefiltered then serves ANY number
+ * of queries (below it, and over a split-bf16 image or none, <= 64 queries are ms_ip_topk as before).  The row count: 1M rows for 1..32
+ * queries, 200k rows for 33..64 (measured: profiles/r05_few_query_image_sweep.log); ms_pf_few_min_rows(nq): the value in force
+ * (the environment variables MS_PF_FEW_MIN_ROWS / MS_PF_FEW2_MIN_ROWS override). */
 #define MS_PF_FEW_MIN_ROWS 1000000
-int64_t ms_pf_few_min_rows(void);
+#define MS_PF_FEW2_MIN_ROWS 200000
+int64_t ms_pf_few_min_rows(int nq);
 #define MS_PF_BF16X3 0
 #define MS_PF_F16X2 1
 #define MS_PF_F16X1 2

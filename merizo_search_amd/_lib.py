@@ -47,7 +47,7 @@ SIGNATURES = {
     "ms_device_cu_count": (_int, []),
     "ms_small_batch_thresholds": (None, [_vp, _vp]),
     "ms_prefilter_max_k": (_int, []),
-    "ms_pf_few_min_rows": (_i64, []),
+    "ms_pf_few_min_rows": (_i64, [_int]),
     "ms_l2_normalize_rows": (_int, [_vp, _i64, _int, _f, _vp]),
     "ms_l2_normalize_rows_to": (_int, [_vp, _vp, _i64, _int, _f, _vp]),
     "ms_row_inv_norms": (_int, [_vp, _i64, _int, _f, _vp, _vp]),

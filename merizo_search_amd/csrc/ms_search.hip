@@ -645,10 +645,11 @@ int block_merge_setting() {
     return v;
 }
 
-int64_t pf_few_min_rows() {         // <= 64 queries take the fp16-image scan from this many rows (MS_PF_FEW_MIN_ROWS overrides)
-    static int64_t v = -1;
-    if (v < 0) { const char *e = getenv("MS_PF_FEW_MIN_ROWS"); v = e ? atoll(e) : (int64_t)MS_PF_FEW_MIN_ROWS; }
-    return v;
+int64_t pf_few_min_rows(int nq) {   // <= 64 queries take the fp16-image scan from this many rows: 1..32 queries (one query tile, HBM-bound) / 33..64 (two tiles)
+    static int64_t v1 = -1, v2 = -1;
+    if (v1 < 0) { const char *e = getenv("MS_PF_FEW_MIN_ROWS"); v1 = e ? atoll(e) : (int64_t)MS_PF_FEW_MIN_ROWS; }
+    if (v2 < 0) { const char *e = getenv("MS_PF_FEW2_MIN_ROWS"); v2 = e ? atoll(e) : (int64_t)MS_PF_FEW2_MIN_ROWS; }
+    return nq > 32 ? (v2 < v1 ? v2 : v1) : v1;
 }
 
 #ifndef MS_PF_SAMPLE_COEF_DEFAULT
@@ -1075,7 +1076,7 @@ void ms_small_batch_thresholds(int *fused_merge_max_nq, int *inkernel_norm_max_n
     if (inkernel_norm_max_nq != nullptr) *inkernel_norm_max_nq = inkernel_norm_setting();
 }
 int ms_prefilter_max_k(void) { return MS_PREFILTER_MAX_K; }
-int64_t ms_pf_few_min_rows(void) { return pf_few_min_rows(); }
+int64_t ms_pf_few_min_rows(int nq) { return pf_few_min_rows(nq); }
 
 int ms_l2_normalize_rows(float *x, int64_t n, int d, float eps, ms_stream_t stream) {
     if (d != MS_DIM) MS_FAIL(MS_ERR_ARG, "ms_l2_normalize_rows: d must be %d (got %d)", MS_DIM, d);
@@ -1264,7 +1265,7 @@ PfLayout pf_layout(int64_t n, int nq, int k, int mode, bool image, int format = 
     // without an image the rows are split in registers (round 3's kernel: inner-product modes only, the loader-wave form)
     // (one or two query tiles -- the reference's own CLI regime -- are HBM-bound: over the fp16 image the scan reads half the bytes of
     //  the fp32 rows; worth the fixed cost of the pipeline around it from a few million rows: pf_few_min_rows)
-    const bool few_ok = image && format != MS_PF_BF16X3 && n >= pf_few_min_rows();
+    const bool few_ok = image && format != MS_PF_BF16X3 && n >= pf_few_min_rows(nq);
     L.ok = prefilter_setting() && L.kp > 0 && n >= 65536 && (L.exact.qwb == 4 || few_ok) &&
            (image ? (ip || mode == MS_MODE_COSINE_UNIT) : (ip && loader_wave_setting() != 0));
     L.exact_grid_max = L.exact.grid; L.exact_P_max = L.exact.P;

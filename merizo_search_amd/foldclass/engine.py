@@ -169,8 +169,8 @@ class HipEngine:
 
     def _image_for(self, pf_image, n: int, nq: int, k: int):
         """The image this batch is searched over, or None (fp32 scan / rows split in registers).  Large batches: the database's
-        image in the arithmetic chosen for it.  <= 64 queries over an fp16 image of >= ms_pf_few_min_rows() rows: the HBM-bound regime
-        at half the bytes -- up to 32 queries with the tighter two-instruction arithmetic (the matrix pipe has time to spare there)."""
+        image in the arithmetic chosen for it.  <= 64 queries over an fp16 image of >= ms_pf_few_min_rows(nq) rows: the HBM-bound regime
+        at half the bytes (33..64 queries: one fp16 pass instead of two query tiles of fp32 matrix work) -- up to 32 queries with the tighter two-instruction arithmetic (the matrix pipe has time to spare there)."""
         ops = self._ops
         if pf_image is None:
             return None

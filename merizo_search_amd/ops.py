@@ -260,14 +260,14 @@ def small_batch_thresholds():
 def prefilter_serves(n: int, nq: int, k: int, image=None) -> bool:
     """The shapes ms_ip_topk_prefiltered serves itself (everything else it hands to ms_ip_topk): ONE statement of the rule for the
     engine, the bench and the tests (the library applies the same in pf_layout).  More than 64 queries, k <= 48, >= 65,536 rows; and,
-    over an fp16 `image` (a PfImage, or a format), ANY number of queries from ms_pf_few_min_rows() rows on (the HBM-bound regime at
-    half the bytes)."""
+    over an fp16 `image` (a PfImage, or a format), ANY number of queries from ms_pf_few_min_rows(nq) rows on (1M rows for 1..32 queries:
+    the HBM-bound regime at half the bytes; 200k rows for 33..64: two query tiles of fp32 matrix work against one fp16 pass)."""
     if k > _lib.PREFILTER_MAX_K or n < _lib.PREFILTER_MIN_ROWS:
         return False
     if nq > 64:
         return True
     fmt = image.format if isinstance(image, PfImage) else image
-    return fmt in (PF_F16X2, PF_F16X1) and n >= int(_lib.load().ms_pf_few_min_rows())
+    return fmt in (PF_F16X2, PF_F16X1) and n >= int(_lib.load().ms_pf_few_min_rows(int(nq)))
 
 
 def _pf_args(db, image, q, mode, lengths, qlen):

@@ -444,11 +444,12 @@ def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, t
     torch = torch_gpu
     from merizo_search_amd import ops, _lib
     from oracle import oracle as orc
-    assert int(_lib.load().ms_pf_few_min_rows()) == 1_000_000
+    assert int(_lib.load().ms_pf_few_min_rows(1)) == 1_000_000 and int(_lib.load().ms_pf_few_min_rows(32)) == 1_000_000
+    assert int(_lib.load().ms_pf_few_min_rows(33)) == 200_000 and int(_lib.load().ms_pf_few_min_rows(64)) == 200_000
     n = 1_050_000
     db, q = _norm_db(n, seed=561), _norm_db(nq, seed=562 + nq)
     assert ops.prefilter_serves(n, nq, k, {"f16x2": ops.PF_F16X2, "f16x1": ops.PF_F16X1}[image]) and not ops.prefilter_serves(n, nq, k)
-    assert not ops.prefilter_serves(n, nq, k, ops.PF_BF16X3) and not ops.prefilter_serves(990_000, nq, k, ops.PF_F16X2)
+    assert not ops.prefilter_serves(n, nq, k, ops.PF_BF16X3) and not ops.prefilter_serves(990_000 if nq <= 32 else 190_000, nq, k, ops.PF_F16X2)
     _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=9, raw=(nq % 2 == 1), expect_fallback=False, image=image)
 
 
@@ -509,3 +510,17 @@ def test_few_queries_whose_proof_fails_get_the_exact_pass_too(nq, owners, image,
     for j, qi in enumerate(owners):
         db[rows[j]] = _family(rng, q[qi], 200)
     _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=17, expect_flagged=len(owners), image=image)
+
+
+@pytest.mark.parametrize("nq", [33, 48, 64])
+def test_two_query_tiles_take_the_fp16_image_scan_from_200k_rows(nq, torch_gpu):
+    """33..64 queries are two query tiles of fp32 matrix work in ms_ip_topk; over the fp16 image they are one pass at the inner-product
+    rate: served from 200k rows (ms_pf_few_min_rows(nq)); 32 queries on the same database are not (HBM-bound: 1M rows).  == the oracle."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n, k = 210_000, 10
+    db, q = _norm_db(n, seed=601), _norm_db(nq, seed=602 + nq)
+    assert ops.prefilter_serves(n, nq, k, ops.PF_F16X1) and not ops.prefilter_serves(n, 32, k, ops.PF_F16X1)
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=5, expect_fallback=False, image="f16x1")
+    _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=5, expect_fallback=False, image="f16x2", raw=True)

@@ -168,7 +168,7 @@ def attach_committed_traffic(roof, pmc_name):
 def measure_traffic_live(kernels, log, timeout_s=150):
     """HBM bytes per launch of the top-level step's scan kernel, measured NOW: two `rocprofv3 --kernel-trace --pmc <counter>` CHILD passes
     (FETCH_SIZE; WRITE_SIZE: counters that cannot share a pass) of this very script on the same workload (`--no-extras --no-cpu-baseline
-    --no-prefilter --steps 5 --warmup 3`), corrected as MI355X_MICROARCH.md prescribes (KiB units; gfx950 reports half of a wide /
+    --no-live-traffic --steps 5 --warmup 3`), corrected as MI355X_MICROARCH.md prescribes (KiB units; gfx950 reports half of a wide /
     LDS-DMA read stream: reads = 2 x FETCH_SIZE x 1024).  The children are started as fresh processes (nothing is exec'd in this one) under
     a hard time limit and killed as a group past it.  -> (bytes per launch, launches counted) or None (no rocprofv3, a pass failed or
     timed out: the caller keeps the figure of the committed profile and says so).  `kernels`: {key: kernel-name substring}; -> {key:
@@ -733,6 +733,11 @@ def compact_line(doc, full_path=None):
     for key in ("recall_at_k", "planted_recall", "topk_identical_to_torch_bruteforce", "weak_scaling_ref_q_per_s", "vs_ref"):
         if doc.get(key) is not None:
             line[key] = _r(doc[key])
+    co = doc.get("collective")
+    if co:          # N > 1: what moved the bytes, between how many DISTINCT devices, and what the exchange + merge cost by itself
+        line["collective"] = {"backend": _r(co.get("backend")), "world": co.get("world"), "distinct_devices": co.get("distinct_devices"),
+                              "rccl_version": _r(co.get("rccl_version")), "exchange_us": _r(co.get("exchange_us")),
+                              "same_device_selftest": co.get("same_device_selftest")}
     line["roofline"] = _roof_short(doc.get("roofline"))
     pf = doc.get("prefiltered")
     if pf:
@@ -808,6 +813,79 @@ def write_full(doc):
     return None
 
 
+PREFLIGHT_DEADLINE_S = 60.0
+
+
+def _arm_deadline(seconds, what):
+    """A rendezvous or a collective that hangs must cost a minute and name its line, not the driver's whole time limit: every rank dumps
+    its Python stacks to stderr and EXITS when `seconds` pass before `_disarm_deadline` (faulthandler's watchdog thread: works while the
+    main thread sits inside a C call)."""
+    import faulthandler
+    print("[bench] pre-flight: %s (deadline %.0f s)" % (what, seconds), file=sys.stderr, flush=True)
+    faulthandler.dump_traceback_later(seconds, repeat=False, exit=True)
+
+
+def _disarm_deadline():
+    import faulthandler
+    faulthandler.cancel_dump_traceback_later()
+    if os.environ.get("MS_BENCH_FAULT_DUMP"):          # (the long-range diagnostic dump of the self-tests shares faulthandler's one timer)
+        faulthandler.dump_traceback_later(float(os.environ["MS_BENCH_FAULT_DUMP"]), repeat=False, exit=False)
+
+
+def collective_preflight(torch, dist, ops, sharded, dev, world, backend, same_device):
+    """Before the ranks generate 23.4 GB each: prove that the process group works and say what it is.  One 8-byte all-reduce and one
+    PackedExchange round trip (all-gather + ms_topk_merge_strided on a 4 x 3 result) under a 60 s deadline with the stack dump armed;
+    an all-gather of every rank's PCI bus id -> the number of DISTINCT devices the ranks sit on.  backend "nccl" (= RCCL) with fewer
+    distinct devices than ranks is refused (RCCL cannot share a device; a mis-set HIP_VISIBLE_DEVICES would otherwise only show as a hang
+    or as N ranks timing one GPU).  -> the `collective` block of the N > 1 line (exchange_us is filled in after the timed region)."""
+    _arm_deadline(PREFLIGHT_DEADLINE_S, "8-byte all-reduce + one PackedExchange round trip + PCI bus ids over %s, %d ranks" % (backend, world))
+    rank = dist.get_rank()
+    t = torch.full((1,), float(rank + 1), dtype=torch.float64, device=dev)
+    dist.all_reduce(t)
+    assert float(t[0]) == world * (world + 1) / 2.0, "all-reduce returned %r" % float(t[0])
+    ex = sharded.PackedExchange(4, 3, dev)
+    ex.out_s.copy_(torch.arange(12, dtype=torch.float32, device=dev).reshape(4, 3).flip(1) + 100.0 * rank)      # rank r's lists: sorted, rows r*3..
+    ex.out_i.copy_(torch.arange(3, dtype=torch.int64, device=dev)[None, :].repeat(4, 1) + 3 * rank)
+    ex.exchange()
+    ms_, mi_ = ex.merge()
+    torch.cuda.synchronize()
+    assert int(mi_[0, 0]) == 3 * (world - 1) and float(ms_[0, 0]) == 2.0 + 100.0 * (world - 1), "exchange + merge pre-flight returned a wrong list"
+    bus = ops.device_pci_bus_id(dev)
+    ids = [None] * world
+    dist.all_gather_object(ids, "%s|%s" % (os.uname().nodename, bus))
+    _disarm_deadline()
+    distinct = len(set(ids))
+    rccl = None
+    try:
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception:
+        pass
+    info = {"backend": dist.get_backend(), "world": world, "distinct_devices": distinct, "pci_bus_ids": sorted(set(i.split("|", 1)[1] for i in ids)),
+            "rccl_version": rccl, "same_device_selftest": bool(same_device), "exchange_us": None,
+            "preflight": "8-byte all-reduce + PackedExchange round trip passed within %.0f s" % PREFLIGHT_DEADLINE_S}
+    if dist.get_backend() == "nccl" and distinct != world:
+        raise SystemExit("bench.py --gpus %d over RCCL: the %d ranks sit on %d distinct device(s) %s -- one GPU per rank is required "
+                         "(check HIP_VISIBLE_DEVICES / LOCAL_RANK)" % (world, world, distinct, info["pci_bus_ids"]))
+    return info
+
+
+def time_exchange(bench, reps=20):
+    """The exchange step ALONE -- one all-gather of the packed per-shard results + the merge of the S blocks -- in microseconds, mean over
+    `reps` back-to-back rounds between two fences, MAX over ranks: what the N-rank step adds to the one-rank step."""
+    torch = bench.torch
+    bench.ex.exchange(); bench.ex.merge(); bench.fence()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bench.ex.exchange()
+        bench.ex.merge()
+    bench.fence()
+    us = (time.perf_counter() - t0) / reps * 1e6
+    t = torch.tensor([us], dtype=torch.float64, device=bench.db.device)
+    bench.dist.all_reduce(t, op=bench.dist.ReduceOp.MAX)
+    return float(t[0])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -869,12 +947,16 @@ def main():
     dev_index = 0 if same_device else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    collective = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        _arm_deadline(2 * PREFLIGHT_DEADLINE_S, "rendezvous of %d ranks (%s)" % (world, backend))
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        _disarm_deadline()
+        collective = collective_preflight(torch, dist, ops, sharded, dev, world, backend, same_device)
 
     k = args.k
     weak = world > 1 and args.rows is None
@@ -899,6 +981,8 @@ def main():
     checks = bench.check(res, sharded)
     # N > 1 (weak scaling): the same ranks' shard scans without the exchange -- the curve's one-rank reference from the same build
     local_ref = bench.local_rate(max(2, min(steps, 10))) if world > 1 else None
+    if collective is not None:
+        collective["exchange_us"] = time_exchange(bench)
 
     def pf_block(b_fp32, res_fp32, steps_, warm_, prep_s=0.3, pmc=None):
         """The same step through the prefiltered search (the path the driver takes for this shape)."""
@@ -955,6 +1039,7 @@ def main():
             "weak_scaling_ref_note": ("the same ranks' shard scans timed WITHOUT the all-gather and the shard merge (slowest rank): the one-GPU rate on one "
                                       "45.6M-row share; weak scaling holds queries/s constant while the database grows N-fold, so vs_ref is the scaling "
                                       "efficiency against this build's own one-rank point (`python bench.py --gpus 1 --shape c4` measures it alone)") if local_ref else None,
+            "collective": collective,
             "roofline": roof,
             "prefiltered": pf_main,
         }

@@ -11,7 +11,9 @@
  * (FoldClassNet(128), reference programs/Foldclass/dbsearch.py:40).
  * Threading: entry points may be called from any host thread; a WORKSPACE serves one stream at a time (calls that share a workspace
  * must be ordered on one stream: the searches keep lists, counters and the exact pass's launch plan in it between their launches) --
- * concurrent searches take one workspace each.
+ * concurrent searches take one workspace each.  A prefiltered search whose bookkeeping was disturbed all the same (a second stream on
+ * its workspace, a launch aborted half way) does not answer: the exact pass queued behind it finds the re-scoring's verdict missing
+ * and TRAPS (round 6; ms_debug_prefilter_poison is the test's way in).
  *
  * Paths below are relative to /root/reference/merizo_search/programs/Foldclass/.
  */
@@ -39,6 +41,10 @@ int ms_version(void);
 const char *ms_last_error(void);
 int ms_device_count(void);
 int ms_device_cu_count(void);
+/* PCI bus id ("0000:c1:00.0") of HIP's current device into buf (len >= 16): lets the ranks of a multi-GPU run prove that they sit
+ * on DISTINCT devices (bench.py gathers it into every N > 1 line; the reference's own multi-GPU call, faiss.index_cpu_to_all_gpus,
+ * dbsearch.py:228-230, has no such check). */
+int ms_device_pci_bus_id(char *buf, int len);
 /* The few-query shortcuts of ms_ip_topk as this build applies them (defaults 2 and 4; the environment variables
  * MS_FUSED_MERGE_MAX_NQ / MS_INKERNEL_NORM_MAX_NQ override them): up to *fused_merge_max_nq queries the scan launch merges its own
  * lists (one launch per search), up to *inkernel_norm_max_nq queries MS_MODE_IP_NORMQ normalises inside the scan launch. */
@@ -147,7 +153,7 @@ int ms_ip_topk_finish(int64_t n, int64_t row_offset, int nq, int k, float *out_s
  *                    2^15; outside [2^-40, 2^40] the fp16 formats are declined with MS_ERR_RANGE); MS_PF_BF16X3 ignores it.
  * Workspace: ms_ip_topk_prefiltered_workspace_bytes.  _prepare / _scan / _finish: its three stages as for ms_ip_topk
  * (queries + sample pass; the one scan launch; merge + exact re-scoring + the exact pass over the flagged queries).
- * ABI note: ms_version() >= 200 (round 5) -- ms_pf_image_bytes / ms_pf_build_image gained `pf_format` (+ row_norm_bound), the four
+ * ABI note: ms_version() == 210 (round 6: + ms_device_pci_bus_id, ms_debug_prefilter_poison; signatures of 200 unchanged); >= 200 (round 5) -- ms_pf_image_bytes / ms_pf_build_image gained `pf_format` (+ row_norm_bound), the four
  * search entry points gained `pf_format` behind `pf_image`; version 100 callers must be rebuilt (merizo_search_amd/_lib.py checks). */
 #define MS_PREFILTER_MAX_K 48
 /* <= 64 queries (the reference's own CLI regime, dbsearch.py:531-546) are HBM-bound up to 32 queries and two query tiles of fp32
@@ -182,6 +188,9 @@ int ms_ip_topk_prefiltered_finish(const float *db, const void *pf_image, int pf_
 /* Diagnostics (tests; synchronises the device): what the last prefiltered search on this workspace left behind -- *flagged =
  * how many of its queries needed the exact pass (0: every answer was proved), *gate_value == *last_epoch iff any did. */
 int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned int *last_epoch, unsigned int *flagged);
+/* Diagnostics (tests; synchronises the device): overwrite the slot counter and the ticket of this workspace's compaction -- the state
+ * an aborted launch or a second stream would leave.  The next prefiltered search on the workspace must fail loudly. */
+int ms_debug_prefilter_poison(void *workspace, unsigned int slot_counter, unsigned int ticket);
 /* Diagnostics (tools/pf_debug.py): the candidate lists of the last prefiltered search on this workspace, copied to the host
  * (approximate scores float32 [nq][kp], rows int64 [nq][kp]); image: 0 = no image, 1 = the split-bf16 image, 2 = the fp16 image; -1 when the shape is
  * not served by the prefilter. */

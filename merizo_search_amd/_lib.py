@@ -35,7 +35,7 @@ _int = ctypes.c_int
 _f = ctypes.c_float
 _sz = ctypes.c_size_t
 
-ABI_VERSION = 200
+ABI_VERSION = 210
 # prefilter image formats (include/merizo_search_amd.h)
 PF_BF16X3, PF_F16X2, PF_F16X1 = 0, 1, 2
 
@@ -45,6 +45,7 @@ SIGNATURES = {
     "ms_last_error": (ctypes.c_char_p, []),
     "ms_device_count": (_int, []),
     "ms_device_cu_count": (_int, []),
+    "ms_device_pci_bus_id": (_int, [ctypes.c_char_p, _int]),
     "ms_small_batch_thresholds": (None, [_vp, _vp]),
     "ms_prefilter_max_k": (_int, []),
     "ms_pf_few_min_rows": (_i64, [_int]),
@@ -65,6 +66,7 @@ SIGNATURES = {
     "ms_ip_topk_prefiltered_scan": (_int, [_vp, _vp, _int, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _sz, _vp]),
     "ms_ip_topk_prefiltered_finish": (_int, [_vp, _vp, _int, _i64, _i64, _vp, _int, _int, _int, _vp, _vp, _f, _f, _vp, _vp, _vp, _sz, _vp]),
     "ms_debug_prefilter_state": (_int, [_vp, _vp, _vp, _vp]),
+    "ms_debug_prefilter_poison": (_int, [_vp, ctypes.c_uint, ctypes.c_uint]),
     "ms_debug_prefilter_lists": (_int, [_vp, _i64, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge": (_int, [_vp, _vp, _int, _int, _int, _vp, _vp, _vp]),
     "ms_topk_merge_strided": (_int, [_vp, _vp, _i64, _i64, _int, _int, _int, _vp, _vp, _vp]),
@@ -109,7 +111,7 @@ def load() -> ctypes.CDLL:
             raise MerizoHipError(f"{LIB_PATH} does not export {name}") from exc
         fn.restype = res
         fn.argtypes = args
-    # the ABI this module binds: 200 = pf_format in the prefilter entry points (an older library would take shifted arguments)
+    # the ABI this module binds: 200 = pf_format in the prefilter entry points (an older library would take shifted arguments); 210 = + two entry points
     if lib.ms_version() != ABI_VERSION:
         raise MerizoHipError(f"{LIB_PATH} reports ABI version {lib.ms_version()}, this package binds {ABI_VERSION}: rebuild it (make -C {CSRC})")
     _lib = lib

@@ -134,6 +134,17 @@ __device__ __forceinline__ const uint2 *ms_block_merge(const uint2 *ent, char *s
     return fin;
 }
 
+// Gate of the exact pipeline queued behind a prefiltered search (ms_search.hip: ms_rescore_body): gate[0] == epoch -> some query
+// needs it, gate[1] == epoch -> the re-scoring launch of THIS call published its verdict.  A gated launch that finds another epoch in
+// gate[1] has been handed a workspace whose re-scoring never finished its count (a poisoned or shared ticket: include/merizo_search_amd.h
+// "a workspace serves one stream"): it TRAPS -- the flagged queries would otherwise keep an unproven answer with a zero return code.
+// Uniform scalar loads from one line; nothing on the good path but one more compare.
+__device__ __forceinline__ bool ms_gate_closed(const uint32_t *gate, uint32_t epoch) {
+    if (gate == nullptr) return false;
+    if (gate[1] != epoch) __builtin_trap();
+    return gate[0] != epoch;
+}
+
 __device__ __forceinline__ float ms_readlane_f(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }

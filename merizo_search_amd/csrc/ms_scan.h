@@ -71,7 +71,7 @@ struct ScanParams {
     int pf_format = 0;                // ... and its arithmetic: MS_PF_BF16X3 (32-row tiles), MS_PF_F16X2 / MS_PF_F16X1 (64-row tiles)
     int list_sm = 0;                  // the launch writes its per-stream lists STREAM-MAJOR ([stream][query][rank]: a workgroup's lists are one contiguous block;
                                       // the image scans always, the loader-wave kernel when its merge can read them: ScanPlan::list_sm) instead of rank-major
-    uint32_t *prog = nullptr;         // fp16-image scan with 2..16 query groups per row stream: [n_streams][16] progress words (epoch << 16 | tile),
+    uint32_t *prog = nullptr;         // fp16-image scan with 2..16 query groups per row stream: [n_streams][16] progress words (8-bit epoch << 24 | 24-bit tile),
     uint32_t prog_epoch = 0;          // by which the workgroups of a stream keep within one L2 window of each other (ms_scan_pf16.h); NULL: off
     int qpw = 1;                      // ... and the waves per workgroup of that kernel, one query tile each, in fours (1: 4 waves, 2: 8)
     const uint32_t *gate = nullptr;   // NULL, or: the launch does nothing unless *gate == gate_epoch (the exact pipeline behind a
@@ -412,7 +412,7 @@ __device__ __forceinline__ void ms_tile_insert(ScanState<KL> &st, const float (&
 template <int KL, bool AUX, bool UB, bool MAXONLY>
 __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    if (p_in.gate != nullptr && *p_in.gate != p_in.gate_epoch) return;          // (uniform: a scalar load)
+    if (ms_gate_closed(p_in.gate, p_in.gate_epoch)) return;          // (uniform: a scalar load)
     ScanParams p = p_in;
     if (p_in.dev_plan != nullptr) {                                     // (uniform: scalar loads)
         const ScanDevPlan d = *p_in.dev_plan;
@@ -1086,7 +1086,7 @@ __device__ __forceinline__ void ms_split8(const f32x4 &x0, const f32x4 &x1, bf16
 template <int KL, int AUXM, bool SAMPLE, bool PF = false>
 __global__ __launch_bounds__(320, 2) void ms_scan_loader_kernel(const ScanParams p) {
     static_assert(!PF || AUXM == 0, "the prefilter exists for the inner-product modes");
-    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
+    if (ms_gate_closed(p.gate, p.gate_epoch)) return;          // (uniform: a scalar load)
     constexpr bool AUX = AUXM != 0;
     constexpr bool SCALE_IN_CHAIN = AUXM == 1 || (AUXM == 2 && SAMPLE);      // (the sample pass needs every score final)
     extern __shared__ __attribute__((aligned(16))) char smem[];

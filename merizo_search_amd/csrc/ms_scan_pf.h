@@ -89,7 +89,7 @@ template <int KL, int NW, bool SAMPLE, bool MASK>
 __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf2_kernel(const ScanParams p) {
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
     constexpr int PPW = 16 / NW;                       // LDS-DMA pieces of a tile per wave
-    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
+    if (ms_gate_closed(p.gate, p.gate_epoch)) return;          // (uniform: a scalar load)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
     unsigned long long tl_setup = 0, tl_first = 0, tl_loop = 0;
 #endif
-    if (p.gate != nullptr && *p.gate != p.gate_epoch) return;          // (uniform: a scalar load)
+    if (ms_gate_closed(p.gate, p.gate_epoch)) return;          // (uniform: a scalar load)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) char lds_char_t;
     typedef volatile __attribute__((address_space(3))) uint32_t lds_flag_t;
@@ -194,12 +194,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     const bool hist_on = !SAMPLE && p.hist != nullptr && p.lb_s != nullptr;      // (uniform)
     f32x4 qv[16];
     float pre_lb = -INFINITY, pre_stp = 0.0f, pre_qlen = 0.0f;
-    uint32_t pre_magic = MS_PF16_MAGIC;
+    uint32_t pre_magic = MS_PF16_MAGIC, pre_n = (uint32_t)p.n;
     int pre_sr = 0;
     if (has_q) {
         const uint32_t *trailer = reinterpret_cast<const uint32_t *>(reinterpret_cast<const char *>(p.pf_image) + (size_t)((p.n + 63) >> 6) * 16384u);
         pre_magic = trailer[0];
         pre_sr = (int)trailer[1];
+        pre_n = trailer[2];
         const f32x4 *src = reinterpret_cast<const f32x4 *>(p.qn + (size_t)(q_valid ? qidx : 0) * MS_DIM + 64 * h);
 #pragma unroll
         for (int i = 0; i < 16; ++i) qv[i] = src[i];
@@ -262,7 +263,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     {
         const uint32_t magic = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre_magic);
         const int sr = __builtin_amdgcn_readfirstlane(pre_sr);
-        if (magic != MS_PF16_MAGIC) __builtin_trap();          // not an fp16 image of this database: never a silent wrong answer
+        const uint32_t img_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)pre_n);
+        // not an fp16 image, or the image of a database with another row count (n < 2^31): never a silent wrong answer
+        if (magic != MS_PF16_MAGIC || img_n != (uint32_t)p.n) __builtin_trap();
         f32x4 v[16];
         float m = 0.0f;
 #pragma unroll

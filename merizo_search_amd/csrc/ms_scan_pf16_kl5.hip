@@ -63,7 +63,8 @@ __global__ __launch_bounds__(256) void ms_pf16_build_image_kernel(const float *d
 
 int ms_launch_pf16_build_image(const float *db, int64_t n, int sr, void *image, hipStream_t st) {
     const int64_t ntiles = (n + 63) / 64;
-    const int64_t blocks = (2 * ntiles + 3) / 4;
+    int64_t blocks = (2 * ntiles + 3) / 4;
+    if (blocks < 1) blocks = 1;                      // (n == 0: one workgroup writes the trailer of an image without tiles)
     hipLaunchKernelGGL(ms_pf16_build_image_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, db, n, (char *)image, ntiles, sr);
     MS_LAUNCH_CHECK("ms_pf16_build_image_kernel");
     return MS_OK;

@@ -108,7 +108,7 @@ constexpr int MERGE_MAX_P = 1024;
 __global__ __launch_bounds__(256) void ms_partial_merge_kernel(const float *part_s, const uint32_t *part_i, int P,
                                                               int k, int64_t row_offset, float *out_s, int64_t *out_i,
                                                               int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
-    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    if (ms_gate_closed(gate, gate_epoch)) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint2 *pool = reinterpret_cast<uint2 *>(smem);              // [k*k]
     uint2 *list = pool + (size_t)k * k;                         // [k]
@@ -201,7 +201,7 @@ template <int PER>      // lists per lane: P <= 64 * PER
 __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, const uint32_t *part_i, int P, int k,
                                                           int64_t row_offset, float *out_s, int64_t *out_i,
                                                           int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch) {
-    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    if (ms_gate_closed(gate, gate_epoch)) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ms_head_merge_wave<PER>(reinterpret_cast<uint2 *>(smem), part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0,
                             ub_s, ub_i, blockIdx.x, threadIdx.x);
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void ms_block_merge_kernel(const float *part_s
                                                              int64_t row_offset, float *out_s, int64_t *out_i,
                                                              int out_stride, int out_col0, float *ub_s, uint32_t *ub_i, const uint32_t *gate, uint32_t gate_epoch,
                                                              const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
-    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    if (ms_gate_closed(gate, gate_epoch)) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     ms_block_merge_body(smem, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, dp, qmap, sparse, sm_stride);
 }
@@ -337,7 +337,7 @@ template <int VPL>      // values per lane: ranks * P <= 64 * VPL
 // list l) of query q is at l * sm_stride + q * k + r, sm_stride = nq_pad * k; 0: rank-major per query ([query][rank][stream]).
 __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s, int P, int k, int ranks, float *lb, uint32_t *hist,
                                                             float *hstep, const uint32_t *gate, uint32_t gate_epoch, size_t sm_stride) {
-    if (gate != nullptr && *gate != gate_epoch) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
+    if (ms_gate_closed(gate, gate_epoch)) return;      // (the exact pipeline behind a prefiltered search: only when it is needed)
     const int q = blockIdx.x, lane = threadIdx.x;
     const float *ps = part_s + (size_t)q * k * P;              // rank-major [k][P]: the first ranks * P floats
     const int count = ranks * P;
@@ -399,16 +399,21 @@ struct PfCompact {
     float *qn_c, *lb_c, *qlen_c;
     int *qmap;
     ScanDevPlan *dp;
-    uint32_t *gate;          // [0] gate, [1] epoch, [2] flagged count (diagnostics), [4] slot counter, [5] ticket
+    uint32_t *gate;          // [0] gate, [1] epoch, [2] flagged count (diagnostics), [4] slot counter, [5] ticket (never reset: counts on)
     uint32_t epoch;
+    uint32_t ticket_base;    // value of the ticket counter when this call's first workgroup arrives (the host keeps the running total)
     int64_t n;
     int cus, nq;
 };
 // The two counters of the compaction (slot counter, ticket) are plain atomic adds -- 256 workgroups arrive within a few
-// microseconds, and a compare-and-swap loop per arrival (tried: counters tagged with the call's epoch, so that no state could
-// survive an aborted launch) serialises them into O(n^2) retries: +250 us at C2.  The LAST workgroup of the launch zeroes both
-// for the next call; a workspace serves one stream at a time (include/merizo_search_amd.h), and a launch that aborts leaves the
-// HIP context in a sticky error anyway.
+// microseconds, and a compare-and-swap loop per arrival (tried: counters tagged with the call's epoch) serialises them into
+// O(n^2) retries: +250 us at C2.  Round 6: the TICKET is never reset -- it counts on from call to call, the host keeps the running
+// total per workspace (sync_take_tickets) and hands every call the value its first arrival will see (ticket_base): the last
+// workgroup is the one that draws ticket_base + nq - 1.  A counter that is not where the host expects it (a launch that was
+// aborted half way, a second stream sharing the workspace against the header's rule, memory poisoned through
+// ms_debug_prefilter_poison) never produces that ticket, gate[1] keeps the previous call's epoch, and the gated launches queued
+// behind (ms_gate_closed) TRAP instead of leaving the flagged queries with an unproven answer.  The slot counter is still zeroed by
+// the last workgroup (its final value is data-dependent).
 struct PfRescore {
     const float *db, *qn, *as;
     const int64_t *ai;
@@ -523,7 +528,7 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
     if (tid == 0) {
         __threadfence();                                         // (this workgroup's slot is taken before its ticket)
         const uint32_t done = atomicAdd(cp.gate + 5, 1u);
-        if (done == (uint32_t)cp.nq - 1u) {                     // the last workgroup: every flagged query has its slot
+        if (done == cp.ticket_base + (uint32_t)cp.nq - 1u) {    // the last workgroup of THIS call: every flagged query has its slot
             __threadfence();
             const int cnt = (int)atomicAdd(cp.gate + 4, 0u);
             ScanDevPlan d;
@@ -533,8 +538,7 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
             cp.gate[0] = cnt > 0 ? cp.epoch : 0u;
             cp.gate[1] = cp.epoch;
             cp.gate[2] = (uint32_t)cnt;
-            cp.gate[4] = 0u;                                     // (for the next call on this workspace: stream order)
-            cp.gate[5] = 0u;
+            cp.gate[4] = 0u;                                     // (for the next call on this workspace: stream order; the ticket counts on)
         }
     }
 }
@@ -697,7 +701,7 @@ void hist_mark_clean(const void *ws, int64_t n, int nq, int k) {
 // and zeroes itself, one per (workspace pointer, device): calls that share a workspace are serialised by the caller anyway
 // (they share the partial lists), so they may share the block.  64 blocks; a 65th workspace takes over the least recently used
 // one (after a device synchronisation: a rare event).
-struct SyncBlock { const void *ws; int dev; char *mem; uint64_t last_use; };
+struct SyncBlock { const void *ws; int dev; char *mem; uint64_t last_use; uint32_t pf_tickets; };      // pf_tickets: tickets handed out so far = the value of the device's ticket word
 constexpr int SYNC_BLOCKS = 64;
 constexpr size_t SYNC_BYTES = 512;         // [0,256) 64 arrival counters of the in-launch merge; [256] the prefilter's gate word
 SyncBlock g_sync[SYNC_BLOCKS];
@@ -718,13 +722,22 @@ char *sync_block_for(const void *ws) {
         if (lru < 0 || hipDeviceSynchronize() != hipSuccess || hipMemset(g_sync[lru].mem, 0, SYNC_BYTES) != hipSuccess) return nullptr;
         g_sync[lru].ws = ws;
         g_sync[lru].last_use = ++g_sync_clock;
+        g_sync[lru].pf_tickets = 0u;
         return g_sync[lru].mem;
     }
     char *mem = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&mem), SYNC_BYTES) != hipSuccess) return nullptr;
     if (hipMemset(mem, 0, SYNC_BYTES) != hipSuccess) { (void)hipFree(mem); return nullptr; }
-    g_sync[g_sync_used++] = SyncBlock{ws, dev, mem, ++g_sync_clock};
+    g_sync[g_sync_used++] = SyncBlock{ws, dev, mem, ++g_sync_clock, 0u};
     return mem;
+}
+// The re-scoring launch of a prefiltered search draws `count` tickets from the block's ticket word (one per query); -> the value the
+// first of them will see.  Wraps modulo 2^32 like the device counter.
+uint32_t sync_take_tickets(const char *mem, uint32_t count) {
+    std::lock_guard<std::mutex> lock(g_hist_clean_mutex);
+    for (int i = 0; i < g_sync_used; ++i)
+        if (g_sync[i].mem == mem) { const uint32_t base = g_sync[i].pf_tickets; g_sync[i].pf_tickets = base + count; return base; }
+    return 0u;
 }
 int inkernel_norm_setting() {      // MS_MODE_IP_NORMQ: up to this many queries are normalised by the scan's own waves (one batch of row loads)
     static int v = -1;
@@ -1060,7 +1073,7 @@ int prepare_scan(const ScanPlan &pl, const float *db, int64_t n, const float *q,
 
 extern "C" {
 
-int ms_version(void) { return 200; }      // 200: pf_format in the prefilter entry points (round 5)
+int ms_version(void) { return 210; }      // 200: pf_format in the prefilter entry points (round 5); 210: ms_device_pci_bus_id, ms_debug_prefilter_poison (round 6)
 const char *ms_last_error(void) { return ms_err_buf; }
 
 int ms_device_count(void) {
@@ -1070,6 +1083,14 @@ int ms_device_count(void) {
 }
 
 int ms_device_cu_count(void) { return cu_count_cached(); }
+
+int ms_device_pci_bus_id(char *buf, int len) {
+    if (buf == nullptr || len < 16) MS_FAIL(MS_ERR_ARG, "ms_device_pci_bus_id: need a buffer of >= 16 bytes");
+    int dev = 0;
+    MS_HIP_CHECK(hipGetDevice(&dev));
+    MS_HIP_CHECK(hipDeviceGetPCIBusId(buf, len, dev));
+    return MS_OK;
+}
 
 void ms_small_batch_thresholds(int *fused_merge_max_nq, int *inkernel_norm_max_nq) {
     if (fused_merge_max_nq != nullptr) *fused_merge_max_nq = fused_merge_setting();
@@ -1369,7 +1390,7 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         ScanDevPlan *dp = reinterpret_cast<ScanDevPlan *>(ws + L.off_dp);
         PfCompact cp;
         cp.qn_c = qn_c; cp.lb_c = lb_c; cp.qlen_c = qlen_c; cp.qmap = qmap; cp.dp = dp; cp.gate = gate; cp.epoch = epoch; cp.n = n;
-        cp.cus = cu_count_cached(); cp.nq = nq;
+        cp.cus = cu_count_cached(); cp.nq = nq; cp.ticket_base = sync_take_tickets(blk, (uint32_t)nq);
         // ONE launch: merge of the per-stream candidate lists (sparse; stream-major behind the image scans) + exact re-scoring + proof + compaction
         PfRescore ra;
         ra.db = db; ra.qn = sp.qn; ra.as = as; ra.ai = ai; ra.lengths = lengths; ra.qlen = qlen; ra.out_s = out_scores; ra.out_i = out_idx; ra.flag = flag;
@@ -1474,6 +1495,17 @@ int ms_debug_prefilter_state(void *workspace, unsigned int *gate_value, unsigned
     unsigned int w[3] = {0, 0, 0};
     if (hipMemcpy(w, blk + 256, 12, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     *gate_value = w[0]; *last_epoch = w[1]; *flagged = w[2];
+    return 0;
+}
+
+// Diagnostics for the tests (synchronises the device): overwrite the two counters of the compaction in the library-owned block of
+// this workspace -- what an aborted launch, or a second stream on the same workspace, would leave behind.  The next prefiltered
+// search on the workspace must then fail loudly (the gated launch traps: ms_gate_closed), never answer.
+int ms_debug_prefilter_poison(void *workspace, unsigned int slot_counter, unsigned int ticket) {
+    char *blk = sync_block_for(workspace);
+    if (blk == nullptr || hipDeviceSynchronize() != hipSuccess) return -1;
+    const unsigned int w[2] = {slot_counter, ticket};
+    if (hipMemcpy(blk + 256 + 16, w, 8, hipMemcpyHostToDevice) != hipSuccess) return -1;
     return 0;
 }
 

@@ -53,6 +53,7 @@ class LazyPfImage:
 
     def __init__(self, engine, db, row_norm_bound=None):
         self._engine, self._db, self._bound, self._image, self._built = engine, db, row_norm_bound, None, False
+        self._few = 0              # few-query searches seen so far on a database large enough for the image to pay
 
     @property
     def built(self) -> bool:
@@ -69,7 +70,7 @@ class LazyPfImage:
         if ops.prefilter_serves(n, nq, k):
             return self.get()
         if ops.prefilter_serves(n, nq, k, ops.pf_default_format()):
-            self._few = getattr(self, "_few", 0) + 1
+            self._few += 1
             if self._few >= 3:
                 return self.get()
         return None
@@ -180,7 +181,7 @@ class HipEngine:
                 return None
         if not ops.prefilter_serves(n, nq, k, pf_image):
             return None
-        if nq <= 32 and pf_image.format == ops.PF_F16X1:
+        if nq <= 32 and pf_image.format == ops.PF_F16X1 and ops.pf_format_is_auto():      # (a forced MS_PF_FORMAT is what runs: A/B runs measure what they name)
             return pf_image.as_format(ops.PF_F16X2)
         return pf_image
 

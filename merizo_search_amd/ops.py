@@ -339,6 +339,23 @@ def prefilter_flagged(ws) -> int:
     return int(c.value) if e.value != 0 else 0
 
 
+def prefilter_poison(ws, slot_counter: int, ticket: int) -> None:
+    """Diagnostics for the tests (synchronises): overwrite the compaction's slot counter and ticket in the library-owned block of this
+    workspace -- the state an aborted launch or a second stream on the workspace would leave (ms_debug_prefilter_poison).  The next
+    prefiltered search on `ws` must fail loudly."""
+    check(_lib.load().ms_debug_prefilter_poison(ptr(ws), int(slot_counter) & 0xFFFFFFFF, int(ticket) & 0xFFFFFFFF), "ms_debug_prefilter_poison")
+
+
+def device_pci_bus_id(device=None) -> str:
+    """PCI bus id of `device` (default: torch's current device), e.g. '0000:c1:00.0' (ms_device_pci_bus_id)."""
+    import ctypes
+    torch = _lib.require_gpu()
+    buf = ctypes.create_string_buffer(64)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        check(_lib.load().ms_device_pci_bus_id(buf, 64), "ms_device_pci_bus_id")
+    return buf.value.decode()
+
+
 def prefilter_fell_back(ws) -> bool:
     """Diagnostics (synchronises): did any query of the last prefiltered search on this workspace need the exact pass?"""
     return prefilter_flagged(ws) > 0

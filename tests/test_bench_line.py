@@ -72,6 +72,13 @@ def test_line_without_optional_blocks():
     text = bench.compact_line(doc)
     line = json.loads(text)
     assert len(text) < 2048 and line["n_gpus"] == 8 and "cpu_baseline" not in line and "prefiltered" not in line and "more" not in line
+    assert "collective" not in line
+    # an N > 1 document says what moved the bytes (round 6): the line carries it
+    doc["collective"] = {"backend": "nccl", "world": 8, "distinct_devices": 8, "pci_bus_ids": ["0000:%02x:00.0" % (5 + 16 * i) for i in range(8)],
+                         "rccl_version": "2.22.3", "same_device_selftest": False, "exchange_us": 61.25, "preflight": "passed"}
+    line = json.loads(bench.compact_line(doc))
+    assert line["collective"] == {"backend": "nccl", "world": 8, "distinct_devices": 8, "rccl_version": "2.22.3", "exchange_us": 61.25,
+                                  "same_device_selftest": False}
 
 
 def test_write_full_round_trips(tmp_path, monkeypatch):

@@ -409,6 +409,86 @@ except Exception as exc:
     assert "FAILED LOUDLY" in r.stdout or r.returncode != 0
 
 
+def test_a_poisoned_compaction_ticket_fails_loudly_instead_of_leaving_unproven_answers(torch_gpu, tmp_path):
+    """the re-scoring launch recognises its last workgroup by a ticket; a ticket counter that is not where the
+    host expects it (an aborted launch, a second stream on the workspace -- here: ms_debug_prefilter_poison) used to leave gate[0] / the
+    device plan unwritten, the gated exact pass returned at once and the flagged queries kept their UNPROVEN prefilter answer with rc 0.
+    Round 6: the ticket counts on from call to call against a host-side total, and the gated launch traps when the re-scoring's verdict
+    (gate[1] == this call's epoch) is missing.  Clustered data (every query owns a family of near-duplicates: all flagged), three
+    poisonings -- ticket behind, ticket ahead, slot counter + ticket -- each in a child process (a trap poisons the HIP context); the
+    un-poisoned control in the same child answers exactly."""
+    import subprocess
+    import sys
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+n, nq, k = 100000, 96, 10
+d = syn.device_database(n, 0, seed=0, device="cuda:0"); q = syn.device_database(nq, 0, seed=1, device="cuda:0")
+g = torch.Generator(device="cpu"); g.manual_seed(5)
+fam = q.cpu()[:, None, :] + torch.randn((nq, 40, 128), generator=g) * 2e-7          # 40 rows within ~1e-6 of every query: no proof possible
+fam = fam / fam.norm(dim=2, keepdim=True)
+d[torch.arange(nq * 40, device="cuda:0") * 17 + 3] = fam.reshape(-1, 128).cuda()
+img = ops.pf_build_image(d, fmt=ops.PF_F16X1, row_norm_bound=1.0 + 1e-6)
+ws = torch.empty_like(ops.PrefilterWorkspace("cuda:0").get(n, nq, k))
+s0, i0 = ops.ip_topk(d, q, k)
+s1, i1 = ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, image=img, workspace=ws)
+torch.cuda.synchronize()
+assert ops.prefilter_flagged(ws) == nq and torch.equal(i0, i1) and torch.equal(s0.view(torch.int32), s1.view(torch.int32))
+s1, i1 = ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, image=img, workspace=ws)          # (the ticket counts on: a second call is as good)
+torch.cuda.synchronize()
+assert torch.equal(i0, i1)
+print("CONTROL OK", flush=True)
+mode = sys.argv[1]
+ops.prefilter_poison(ws, *{"behind": (0, 5), "ahead": (0, 2 * nq + 7), "both": (3, 1)}[mode])
+try:
+    s2, i2 = ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, image=img, workspace=ws)
+    torch.cuda.synchronize()
+    print("ANSWERED", bool(torch.equal(i0, i2)))
+except Exception as exc:
+    print("FAILED LOUDLY", type(exc).__name__)
+""" % repo
+    for mode in ("behind", "ahead", "both"):
+        r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600)
+        assert "CONTROL OK" in r.stdout, r.stdout + r.stderr[-3000:]
+        assert "ANSWERED" not in r.stdout, mode + ": " + r.stdout + r.stderr[-2000:]
+        assert "FAILED LOUDLY" in r.stdout or r.returncode != 0, mode
+
+
+def test_fp16_image_built_for_another_row_count_traps(torch_gpu):
+    """the trailer's row count is checked by the scan too (an image of the same tile count built for other rows used to
+    answer from the wrong rows): the C ABI called with the image of a 100,000-row database for a 99,990-row one traps.  Child process."""
+    import subprocess
+    import sys
+    import os
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys; sys.path.insert(0, %r)
+import torch
+from merizo_search_amd import ops
+from merizo_search_amd.foldclass import synthetic as syn
+d = syn.device_database(100000, 0, seed=0, device="cuda:0"); q = syn.device_database(100, 0, seed=1, device="cuda:0")
+img = ops.pf_build_image(d, fmt=ops.PF_F16X2, row_norm_bound=1.0 + 1e-6)
+e = ops.pf_build_image(d[:0], fmt=ops.PF_F16X2, row_norm_bound=1.0)        # (ADVICE r05: an empty database builds a trailer-only image)
+torch.cuda.synchronize()
+assert e.data[:4].cpu().numpy().tobytes() == b"MF16"
+small = d[:99990]
+bad = ops.PfImage(img.data, ops.PF_F16X2, 99990)          # (the Python wrapper's own check passes: same tile count, same size)
+try:
+    s, i = ops.ip_topk_prefiltered(small, q, 10, 1.0 + 1e-6, image=bad)
+    torch.cuda.synchronize()
+    print("ANSWERED")
+except Exception as exc:
+    print("FAILED LOUDLY", type(exc).__name__)
+""" % repo
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "ANSWERED" not in r.stdout, r.stdout + r.stderr[-2000:]
+    assert "FAILED LOUDLY" in r.stdout or r.returncode != 0
+
+
 def test_the_arithmetic_is_chosen_per_database_by_searching_its_own_rows(torch_gpu):
     """ops.pf_choose_format (what engine.pf_image runs once per resident database): i.i.d. rows -> one matrix instruction per 16
     dimensions (MS_PF_F16X1); a database made of families of rows within ~4e-4 of each other (cosine) -> two (MS_PF_F16X2), over the same
@@ -438,8 +518,8 @@ def test_the_arithmetic_is_chosen_per_database_by_searching_its_own_rows(torch_g
 @pytest.mark.parametrize("nq,k", [(1, 10), (3, 1), (17, 10), (32, 20), (33, 5), (64, 10), (5, 40), (2, 48)])
 def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, torch_gpu):
     """The reference's own CLI regime (one to a few query domains per call, dbsearch.py:531-546) is HBM-bound: from ms_pf_few_min_rows()
-    rows on, ms_ip_topk_prefiltered serves ANY number of queries over an fp16 image -- 256 B per row instead of 512.  2.1M rows (the
-    threshold is 2M): indices and score bits == the oracle's; nothing flagged on ordinary data; below the threshold, or over a
+    rows on, ms_ip_topk_prefiltered serves ANY number of queries over an fp16 image -- 256 B per row instead of 512.  1.05M rows (the
+    threshold is 1M): indices and score bits == the oracle's; nothing flagged on ordinary data; below the threshold, or over a
     split-bf16 image, the same call is ms_ip_topk (same answers)."""
     torch = torch_gpu
     from merizo_search_amd import ops, _lib

@@ -113,6 +113,69 @@ def test_cli_under_torchrun_two_ranks_gloo_oracle(tmp_path):
         assert a == b, suffix
 
 
+
+def _segment_rows_without_runtime(path):
+    """`_segment.tsv` rows with the wall-clock `time_sec` column (index 6, programs/utils.py:161-176) removed: it is the only field
+    of any output file that differs between two runs of the same command."""
+    return [l.split("\t")[:6] + l.split("\t")[7:] for l in open(path).read().splitlines()]
+
+
+C5_CHOPPING = "71-189,190-290,291-453"          # /root/reference README.md:128 (AF-Q96PD2)
+
+
+def _c5_database_pdbs(tmp_path, count, seed=21):
+    """A directory of `count` synthetic single-domain PDB files (coordinates on the 0.001 grid of the PDB text format) -- the
+    input of createdb -- plus copies of the three AF-Q96PD2 domains of the README chopping, so that the C5 query has real hits."""
+    from merizo_search_amd.foldclass import chopping as chop, pdbio, synthetic as syn
+    dbdir = tmp_path / "c5_pdbs"
+    dbdir.mkdir()
+    names, coords, seqs = syn.synthetic_structures(count, seed=seed, min_len=40, max_len=150)
+    for n, c, s in zip(names, coords, seqs):
+        pdbio.write_pdb(str(dbdir), np.round(c.astype(np.float64), 3).astype(np.float32), s, name=os.path.basename(n).replace(".pdb", ""))
+    pd2 = os.path.join(REPO, "tests", "golden", "AF-Q96PD2-F1-model_v4_ca.pdb")
+    for j, d in enumerate(chop.domains_from_chopping(pd2, C5_CHOPPING, "A")):
+        pdbio.write_pdb(str(dbdir), d["coords"], d["seq"], name="AF-Q96PD2-F1-model_v4_TED%02d" % (j + 1))
+    return pd2, str(dbdir)
+
+
+def _c5_on_eight_ranks(tmp_path, launcher_argv, env, count):
+    """C5 as BASELINE.json words it (easy-search of AF-Q96PD2, README chopping, -k 10) on EIGHT ranks under torchrun against the same
+    command in one process, fed by createdb on eight ranks against createdb in one process: database files and TSVs identical."""
+    from conftest import free_port
+    pd2, dbdir = _c5_database_pdbs(tmp_path, count)
+    port = free_port(4)
+    for nproc, tag in ((8, "db8"), (1, "db1")):
+        r = _torchrun(nproc, launcher_argv + ["createdb", dbdir, str(tmp_path / tag), "--layout", "faiss"], env, port + (0 if nproc == 8 else 1))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    import json
+    info8, info1 = json.load(open(tmp_path / "db8.json")), json.load(open(tmp_path / "db1.json"))
+    assert info8["DB_SIZE"] == info1["DB_SIZE"] == count + 3
+    for key in ("dbfname_IP", "db_names_f", "sif", "sdf", "cif", "cdf"):          # every file of the faiss layout, byte for byte
+        a, b = open(tmp_path / info8[key], "rb").read(), open(tmp_path / info1[key], "rb").read()
+        assert a == b, key
+    search = ["easy-search", pd2, str(tmp_path / "db8"), None, str(tmp_path / "tmp"), "-k", "10", "-s", "-1", "--chopping", C5_CHOPPING, "--output_headers"]
+    for nproc, out in ((8, "eight"), (1, "one")):
+        r = _torchrun(nproc, launcher_argv + [a if a is not None else str(tmp_path / out) for a in search], env, port + (2 if nproc == 8 else 3))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    one, eight = open(str(tmp_path / "one") + "_search.tsv").read(), open(str(tmp_path / "eight") + "_search.tsv").read()
+    assert one == eight                                                            # byte-identical
+    rows = [l.split("\t") for l in one.splitlines()[1:]]
+    assert len(rows) == 30 and {r_[0] for r_ in rows} == {"AF-Q96PD2-F1-model_v4_ca_merizo_0%d" % i for i in (1, 2, 3)}
+    for j, dom in enumerate(("71-189", "190-290", "291-453")):                     # every domain finds its own copy first
+        top = rows[10 * j]
+        assert top[1] == dom and top[4] == "0" and top[5] == "AF-Q96PD2-F1-model_v4_TED%02d" % (j + 1), top
+    seg1, seg8 = _segment_rows_without_runtime(str(tmp_path / "one") + "_segment.tsv"), _segment_rows_without_runtime(str(tmp_path / "eight") + "_segment.tsv")
+    assert seg1 == seg8 and seg1[1][:5] == ["AF-Q96PD2-F1-model_v4_ca", "775", "383", "392", "3"]
+
+
+def test_c5_easy_search_af_q96pd2_on_eight_ranks_gloo_oracle(tmp_path):
+    """C5 verbatim (merizo.py:367-383, README.md:128) on 8 ranks, CPU: gloo + the oracle engine behind the product CLI."""
+    shim = tmp_path / "shim.py"
+    shim.write_text(_CLI_SHIM)
+    env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    _c5_on_eight_ranks(tmp_path, [str(shim), REPO], env, count=21)
+
+
 def test_ranks_wait_out_rank0_postprocessing_beyond_the_group_timeout(tmp_path):
     """Rank 0's serial post-processing (TM-align per hit, multi-domain step, TSV files) may outlast the process group's
     collective timeout: the other ranks wait on the store, not in a collective, so nobody is aborted.
@@ -227,6 +290,18 @@ def test_cli_under_torchrun_two_ranks_on_one_gpu(tmp_path):
         assert open(str(tmp_path / "one") + suffix).read() == open(str(tmp_path / "two") + suffix).read(), suffix
 
 
+
+@pytest.mark.gpu
+def test_c5_easy_search_af_q96pd2_on_eight_ranks_one_gpu(tmp_path):
+    """C5 verbatim on the hardware there is: `torchrun --nproc-per-node 8 -m merizo_search_amd.cli easy-search AF-Q96PD2 ... --chopping
+    71-189,190-290,291-453 -k 10` (eight ranks sharing cuda:0 over gloo: MERIZO_SAME_DEVICE / MERIZO_DIST_BACKEND; the HIP engine on every
+    shard, 16 rows per shard -- fewer than k + the padded lists through the all-gather) against the one-process run: `_search.tsv`
+    byte-identical, `_segment.tsv` identical but for its wall-clock column; the database comes from createdb on 8 ranks and is byte-identical
+    to the one createdb writes in one process."""
+    env = dict(os.environ, MERIZO_DIST_BACKEND="gloo", MERIZO_SAME_DEVICE="1", MERIZO_ALLOW_SYNTHETIC_WEIGHTS="1", PYTHONPATH=REPO, GLOO_SOCKET_IFNAME="lo")
+    _c5_on_eight_ranks(tmp_path, ["-m", "merizo_search_amd.cli"], env, count=125)
+
+
 @pytest.mark.gpu
 def test_rccl_exchange_runs_at_world_size_one(tmp_path):
     """RCCL itself on the hardware there is: a 1-rank "nccl" group, PackedExchange's all_gather_into_tensor
@@ -293,6 +368,13 @@ def _bench_line(stdout):
     for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert key in line["roofline"], key
     assert "workload" in line["config"] and line["dtype"] == "f32"
+    if line["n_gpus"] > 1:          # an N > 1 line proves what ran: backend, ranks, DISTINCT devices, RCCL version, the exchange's own time
+        co = line["collective"]
+        for key in ("backend", "world", "distinct_devices", "rccl_version", "exchange_us", "same_device_selftest"):
+            assert key in co, key
+        assert co["world"] == line["n_gpus"] and co["exchange_us"] > 0 and co["distinct_devices"] >= 1
+    else:
+        assert "collective" not in line
     return line
 
 
@@ -307,6 +389,7 @@ def test_bench_gpus_2_self_launches_and_is_exact(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = _bench_line(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["rows_per_gpu"] == 300000
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["distinct_devices"] == 1 and line["collective"]["same_device_selftest"] is True
     assert line["weak_scaling_ref_q_per_s"] > 0 and 0.2 < line["vs_ref"] <= 1.05       # the exchange + merge cost something, not much
     assert line["recall_at_k"] == 1.0 and line["planted_recall"] == 1.0
     assert line["topk_identical_to_torch_bruteforce"].startswith("96 of 96")
@@ -324,6 +407,7 @@ def test_bench_gpus_8_self_launches_on_tiny_shards(tmp_path):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = _bench_line(r.stdout)
     assert line["n_gpus"] == 8 and line["config"]["rows_per_gpu"] == 100000
+    assert line["collective"]["backend"] == "gloo" and line["collective"]["world"] == 8 and line["collective"]["distinct_devices"] == 1
     assert line["weak_scaling_ref_q_per_s"] > 0 and line["vs_ref"] > 0
     assert line["recall_at_k"] == 1.0 and line["planted_recall"] == 1.0
     assert line["topk_identical_to_torch_bruteforce"].startswith("96 of 96")

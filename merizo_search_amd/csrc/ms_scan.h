@@ -50,6 +50,10 @@ struct ScanParams {
     float mincov;
     float qnorm_eps;        // > 0: qn is the caller's RAW query array; every wave L2-normalises its query tile itself (x / max(|x|, eps),
                             //      the arithmetic of ms_normalize_rows_kernel) -- the kernels for 1-2 query tiles only
+    float qraw_eps = 0.0f;  // > 0 (fp16-image scans of the prefilter only, round 6): qn is the caller's RAW query array and every wave normalises its
+                            //      query tile in its set-up, APPROXIMATELY (q * (1 / max(|q|, eps)): a few ulp from F.normalize, far inside the scan's
+                            //      error bound; the sample pass and the scan run the same sequence) -- the exact normalisation the answer needs is
+                            //      done by the re-scoring launch, one query per workgroup (ms_rescore_body): no query-preparation launch at all
     int unit_rows;          // MS_MODE_COSINE_UNIT: the rows are L2-normalised already (no inv_norm array); lengths / qlen mask as usual
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;

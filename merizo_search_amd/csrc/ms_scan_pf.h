@@ -60,9 +60,13 @@ static_assert(PF2_W >= 2 && PF2_D - PF2_W >= 1 && PF2_R >= PF2_D + PF2_W - 1, "r
 constexpr int PF2_AUXR = 16;                   // aux ring: the row lengths of a tile (256 B per slot), cosine mode
 constexpr int PF2_CAND = 4;                    // candidates a lane buffers before the lists take them
 constexpr int PF2_OFF_AUX = PF2_R * 16384;
-constexpr int PF2_OFF_HIST = PF2_OFF_AUX + PF2_AUXR * 256;      // the shared bound's counters of a wave's 32 queries, staged by LDS-DMA: 2 KiB; waves
-                                                                // w and w + 4 take turns at area w & 3 (half a period apart)
-constexpr int PF2_OFF_CAND = PF2_OFF_HIST + 4 * 2048;           // [wave][slot][lane] (score, row): 512 B per slot
+#ifndef MS_PF2_HIST_AREAS
+#define MS_PF2_HIST_AREAS 4
+#endif
+constexpr int PF2_HIST_AREAS = MS_PF2_HIST_AREAS;               // 4: waves w and w + 4 take turns at area w & 3 (half a period of 16 tiles apart); 8: one per wave
+static_assert(PF2_HIST_AREAS == 4 || PF2_HIST_AREAS == 8, "staging areas of the shared bound");
+constexpr int PF2_OFF_HIST = PF2_OFF_AUX + PF2_AUXR * 256;      // the shared bound's counters of a wave's 32 queries, staged by LDS-DMA: 2 KiB per area
+constexpr int PF2_OFF_CAND = PF2_OFF_HIST + PF2_HIST_AREAS * 2048;           // [wave][slot][lane] (score, row): 512 B per slot
 constexpr int PF2_ARR = 16;                                     // arrival counters: one per tile modulo 16, counting up by NW per reuse
 constexpr int PF2_OFF_CNT = PF2_OFF_CAND + 8 * PF2_CAND * 512;  // arrived[16]
 constexpr int PF2_OFF_DUMMY = PF2_OFF_CNT + 64;                 // cosine mode: where the waves other than 0 drop their (unused) aux piece

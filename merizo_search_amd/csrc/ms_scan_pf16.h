@@ -11,7 +11,9 @@
 //   the exact scan):  row rounding 2^-11 = 4.883e-4;  [F16X1: query rounding 2^-11 more, cross term 2^-22]  query residual 2^-22 =
 //   2.4e-7;  components that fall below the fp16 normal range AFTER scaling (row_i < 2^-28 B, q_i < 2^-27 max|q|), flushed or not:
 //   2 x 8.4e-8;  fp32 accumulation of 256 (128) products inside the matrix pipe, truncating at worst: 256 x 2^-23 = 3.05e-5;  the
-//   exact chain's own 128 roundings: 7.6e-6.  Sum 5.27e-4 (F16X2), 1.00e-3 (F16X1); MS_PF_ERR_* round up.  tools/stress_prefilter.py
+//   exact chain's own 128 roundings: 7.6e-6;  [round 6, raw queries normalised in the scan's set-up: q * (1 / max(|q|, eps)) instead of
+//   F.normalize's q / max(|q|, eps), the sum of squares in another order: <= 4 ulp of fp32 = 4.8e-7].  Sum 5.27e-4 (F16X2), 1.00e-3 (F16X1);
+//   MS_PF_ERR_* round up.  tools/stress_prefilter.py
 //   measures max |a - s| / (|row||q|) over random shapes against these.
 //   Range: the image holds row * 2^sr, sr = 14 - floor(log2 B), so every component is below 2^15 (clamped to +-65504 should B have
 //   been wrong: an fp16 inf would turn a row's scores into NaN, which no filter passes); each query goes in as q * 2^sq with its largest
@@ -35,6 +37,12 @@ constexpr uint32_t MS_PF16_MAGIC = 0x3631464du;       // "MF16"
 #define MS_PF_ERR_F16X1 1.05e-3f
 #ifndef MS_PF16_SHADOW
 #define MS_PF16_SHADOW 0
+#endif
+#ifndef MS_PF16_HIST_PERIOD
+#define MS_PF16_HIST_PERIOD MS_HIST_PERIOD     // tiles between two looks at the shared bound in this kernel (8 needs MS_PF2_HIST_AREAS = 8)
+#endif
+#ifndef MS_PF16_GROUPED
+#define MS_PF16_GROUPED 1          // the rare path looks for candidates group of four registers by group (0: sixteen ballots, rounds 4-5)
 #endif
 
 // The approximate score of (row, query): one accumulator chain per half tile, k blocks in order, per block rowh.qh [, rowh.ql].
@@ -268,9 +276,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         if (magic != MS_PF16_MAGIC || img_n != (uint32_t)p.n) __builtin_trap();
         f32x4 v[16];
         float m = 0.0f;
+        float rinv = 1.0f;
+        if (p.qraw_eps > 0.0f) {            // (uniform) raw queries: q / max(|q|, eps) to a few ulp -- this lane's 64 squares in order, then the partner's
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { ss += qv[i].x * qv[i].x; ss += qv[i].y * qv[i].y; ss += qv[i].z * qv[i].z; ss += qv[i].w * qv[i].w; }
+            ss = ss + ms_xor32_f(ss, h);
+            rinv = 1.0f / fmaxf(sqrtf(ss), p.qraw_eps);
+        }
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            v[i] = q_valid ? qv[i] : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            v[i] = q_valid ? qv[i] * rinv : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v[i].x), fabsf(v[i].y)), fmaxf(fabsf(v[i].z), fabsf(v[i].w))));
         }
         m = fmaxf(m, ms_xor32_f(m, h));
@@ -368,8 +384,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         if (mask_on) apply_mask(sc_v, t, half);
         const uint32_t sub_row0 = (uint32_t)(row_begin + (int64_t)t * 64) + (uint32_t)(32 * half + 4 * h);
         uint32_t regs = 0;                                   // registers holding a candidate of some lane (uniform)
+#if MS_PF16_GROUPED
+        // Round 6: sixteen ballots (~64 instructions, candidate or not) were half of a typical visit.  The lane's maximum over each GROUP of
+        // four registers (rows 8 g + 4 h + 0..3: eight instructions), one ballot per group, and the four ballots of a group only where its
+        // maximum passes: 8 + 12 + 16 instructions for the usual visit (one register of one group).
+        {
+            float g0, g1, g2, g3;
+            asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %8, %9, %10\n\tv_max3_f32 %2, %12, %13, %14\n\tv_max3_f32 %3, %16, %17, %18\n\t"
+                "v_max_f32 %0, %0, %7\n\tv_max_f32 %1, %1, %11\n\tv_max_f32 %2, %2, %15\n\tv_max_f32 %3, %3, %19"
+                : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+                : "v"(sc_v[0]), "v"(sc_v[1]), "v"(sc_v[2]), "v"(sc_v[3]), "v"(sc_v[4]), "v"(sc_v[5]), "v"(sc_v[6]), "v"(sc_v[7]), "v"(sc_v[8]),
+                  "v"(sc_v[9]), "v"(sc_v[10]), "v"(sc_v[11]), "v"(sc_v[12]), "v"(sc_v[13]), "v"(sc_v[14]), "v"(sc_v[15]));
+#define MS_PF16_GROUP(G, GM)                                                                                             \
+            if (__ballot(GM > tau_s) != 0) {                                                                             \
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) regs |= (__ballot(sc_v[4 * (G) + j] > tau_s) != 0 ? 1u : 0u) << (4 * (G) + j); \
+            }
+            MS_PF16_GROUP(0, g0) MS_PF16_GROUP(1, g1) MS_PF16_GROUP(2, g2) MS_PF16_GROUP(3, g3)
+#undef MS_PF16_GROUP
+        }
+#else
 #pragma unroll
         for (int i = 0; i < 16; ++i) regs |= (__ballot(sc_v[i] > tau_s) != 0 ? 1u : 0u) << i;
+#endif
 #pragma unroll 1
         while (regs != 0u) {
             const int i = __builtin_ctz(regs);
@@ -552,15 +588,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         // it (counted by all waves so far) bounds the k-th best.  Waves w and w + 4 share staging area w & 3: wave w fetches in
         // phase 2 w of a period and reads in phase 2 w + 2, so the two are half a period (>= 8 tiles) apart, and no wave runs
         // more than max(W - 1, R - D) tiles ahead of another.
-        const int fetch_phase = 2 * wave, read_phase = (2 * wave + 2) & (MS_HIST_PERIOD - 1);
+        // (round 6, MS_PF2_HIST_AREAS = 8: every wave has a staging area of its own and the period may be 8 tiles -- the first look at the
+        //  shared bound comes at tile 2..8 instead of 2..16 and every 8 tiles from then on: C2's 61-tile streams see it 7 times, not 3-4)
+        constexpr int HP = MS_PF16_HIST_PERIOD;
+        static_assert(HP == 16 || (HP == 8 && (PF2_HIST_AREAS == 8 || NW == 4)), "a shared staging area needs half a period of 16 tiles between its two users");
+        const int fetch_phase = (HP == 16 ? 2 * wave : 2 * (wave & 3)), read_phase = (fetch_phase + 2) & (HP - 1);
+        const int hist_area = wave & (PF2_HIST_AREAS - 1);
         auto hist_step = [&](int t) __attribute__((always_inline)) {
-            const int phase = t & (MS_HIST_PERIOD - 1);
+            const int phase = t & (HP - 1);
             if (phase == fetch_phase) {
                 const uint64_t hb = (uint64_t)(uintptr_t)p.hist + (uint64_t)qtile * 2048u;
                 const uint32_t hb_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)hb);
                 const uint32_t hb_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(hb >> 32));
                 const uint64_t shb = ((uint64_t)hb_hi << 32) | (uint64_t)hb_lo;
-                const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(ring_lds + PF2_OFF_HIST + (uint32_t)(wave & 3) * 2048u);
+                const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane(ring_lds + PF2_OFF_HIST + (uint32_t)hist_area * 2048u);
                 ms_glds_s16_sc1<0>(dst, voff, shb);
                 ms_glds_s16_sc1<1024>(dst + 1024, voff, shb);
             }
@@ -568,7 +609,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
                 PF2_T0();
                 // the two stages since then issued two tiles' pieces behind the counters' (near the end of a stream: fewer -- drain)
                 if (t - 1 + PF2_D < ntl) wait_own(std::integral_constant<int, 2>{}); else ms_pf2_vmcnt<0>();
-                const ms_u32x4 *hp = reinterpret_cast<const ms_u32x4 *>(smem + PF2_OFF_HIST + (wave & 3) * 2048 + r * 64);
+                const ms_u32x4 *hp = reinterpret_cast<const ms_u32x4 *>(smem + PF2_OFF_HIST + hist_area * 2048 + r * 64);
                 const ms_u32x4 c0 = hp[0], c1 = hp[1], c2 = hp[2], c3 = hp[3];
                 const uint32_t c[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};
                 uint32_t cum = 0;

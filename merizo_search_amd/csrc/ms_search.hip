@@ -423,6 +423,7 @@ struct PfRescore {
     uint32_t *flag;
     int64_t row_offset;
     float err_coef, mincov;
+    float q_eps;             // > 0: qn is the caller's RAW query array -- the workgroup normalises its query itself, exactly (round 6)
     int k, kp, fp16_range;
     PfCompact cp;
 };
@@ -439,8 +440,22 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
     const int k = a.k, kp = a.kp;
     const PfCompact &cp = a.cp;
     if (act) {
-        qs[lane] = a.qn[(size_t)q * MS_DIM + lane];
-        qs[64 + lane] = a.qn[(size_t)q * MS_DIM + 64 + lane];
+        if (a.q_eps > 0.0f) {
+            // raw query: F.normalize (dbsearch.py:303-304, eps 1e-12) / cosine_similarity's own normalisation (dbsearch.py:78, eps 1e-8) in the
+            // arithmetic of ms_normalize_rows_kernel -- float2 per lane, the same butterfly sum, sqrt, max, divide: the same bits -- which
+            // is what the exact scores below (and the exact pass's copy of the query) are made of; the image scan in front of this launch
+            // normalised the same query approximately, which is all its error bound asks for (ms_scan_pf16.h)
+            float2 v = *(reinterpret_cast<const float2 *>(a.qn + (size_t)q * MS_DIM) + lane);
+            const float ss = wave_sum(v.x * v.x + v.y * v.y);
+            const float nrm = fmaxf(sqrtf(ss), a.q_eps);
+            v.x = v.x / nrm;
+            v.y = v.y / nrm;
+            qs[2 * lane] = v.x;
+            qs[2 * lane + 1] = v.y;
+        } else {
+            qs[lane] = a.qn[(size_t)q * MS_DIM + lane];
+            qs[64 + lane] = a.qn[(size_t)q * MS_DIM + 64 + lane];
+        }
         if (lane == 0) kth = -INFINITY;
     }
     __syncthreads();
@@ -528,6 +543,10 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
     if (tid == 0) {
         __threadfence();                                         // (this workgroup's slot is taken before its ticket)
         const uint32_t done = atomicAdd(cp.gate + 5, 1u);
+        // this call's nq tickets are ticket_base .. ticket_base + nq - 1: any other value means the counter was not where the host's
+        // running total says (behind: the first arrival sees it; ahead by less than nq: the "last" ticket would be drawn EARLY, by a
+        // workgroup that is not the last, and the late arrivals see it here) -- trap, never an unproven answer
+        if (done - cp.ticket_base >= (uint32_t)cp.nq) __builtin_trap();
         if (done == cp.ticket_base + (uint32_t)cp.nq - 1u) {    // the last workgroup of THIS call: every flagged query has its slot
             __threadfence();
             const int cnt = (int)atomicAdd(cp.gate + 4, 0u);
@@ -1253,6 +1272,11 @@ int pace_setting() {
     if (v < 0) { const char *e = getenv("MS_PF_PACE"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = the query groups of a row stream run free
     return v;
 }
+int pf_rawq_setting() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("MS_PF_RAWQ"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the prepared (normalised) copy of the queries
+    return v;
+}
 int prefilter_setting() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("MS_PREFILTER"); v = e ? atoi(e) : 1; }      // diagnostics: 0 = always the fp32 scan
@@ -1343,15 +1367,23 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
     char *ws = (char *)workspace;
     const ScanPlan &pl = L.pf;
     ScanParams sp;
+    // Raw queries over the fp16 image (MS_MODE_IP_NORMQ, MS_MODE_COSINE_UNIT; round 6): no query-preparation launch -- the sample pass and the
+    // scan read the caller's array and normalise approximately in their set-up, the re-scoring launch normalises exactly (MS_PF_RAWQ=0: the
+    // prepared copy as before)
+    const float rawq_eps = (image != nullptr && format != MS_PF_BF16X3 && (mode == MS_MODE_IP_NORMQ || mode == MS_MODE_COSINE_UNIT) &&
+                            ((uintptr_t)q & 15) == 0 && pf_rawq_setting()) ? (mode == MS_MODE_IP_NORMQ ? 1e-12f : 1e-8f) : 0.0f;
     if (stages & 1) {
-        rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, lengths, qlen, mincov, ws, st, &sp);
+        if (rawq_eps > 0.0f) fill_scan_params(pl, db, n, q, nq, nullptr, lengths, qlen, mincov, ws, mode, &sp);
+        else rc = prepare_scan(pl, db, n, q, nq, mode, nullptr, lengths, qlen, mincov, ws, st, &sp);
         if (rc) return rc;
+        if (rawq_eps > 0.0f) { sp.qn = q; sp.qnorm_eps = 0.0f; sp.qraw_eps = rawq_eps; }
         sp.prefilter = 1; sp.pf_image = image; sp.pf_format = format;
         rc = run_prepass(pl, &sp, nq, ws, st);
         if (rc) return rc;
         if (sp.hist != nullptr) hist_mark_clean(workspace, n, nq, L.kp);
     } else {
         fill_scan_params(pl, db, n, q, nq, nullptr, lengths, qlen, mincov, ws, mode, &sp);
+        if (rawq_eps > 0.0f) { sp.qn = q; sp.qnorm_eps = 0.0f; sp.qraw_eps = rawq_eps; }
         sp.prefilter = 1; sp.pf_image = image; sp.pf_format = format;
         if (pl.prepass_tiles > 0) {
             sp.lb_s = reinterpret_cast<const float *>(ws + pl.off_lb_s);
@@ -1395,6 +1427,7 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         PfRescore ra;
         ra.db = db; ra.qn = sp.qn; ra.as = as; ra.ai = ai; ra.lengths = lengths; ra.qlen = qlen; ra.out_s = out_scores; ra.out_i = out_idx; ra.flag = flag;
         ra.row_offset = row_offset; ra.err_coef = pf_err_coef(image != nullptr, format) * row_norm_bound; ra.mincov = mincov;
+        ra.q_eps = rawq_eps;
         ra.k = k; ra.kp = L.kp; ra.fp16_range = (image != nullptr && format != MS_PF_BF16X3) ? 1 : 0; ra.cp = cp;
         const size_t block_lds = (size_t)MS_BLOCK_MERGE_SCRATCH + (((size_t)L.kp * pl.P + 3) & ~(size_t)3) * sizeof(uint2);
         if (block_lds > 156 * 1024 || pl.P > 256) MS_FAIL(MS_ERR_RANGE, "internal: %d candidate lists of %d entries exceed the merge", pl.P, L.kp);

@@ -81,6 +81,19 @@ def test_line_without_optional_blocks():
                                   "same_device_selftest": False}
 
 
+def test_line_carries_the_streamed_headline():
+    """Round 6: the `streamed` block (host memmap over PCIe) puts its two headline numbers under `more`."""
+    doc = _doc()
+    doc["streamed"] = {"bound": "pcie", "peak_GBps": 63.0, "roofline": {"bound": "pcie", "achieved": 38.123, "peak": 63.0, "unit": "GB/s", "frac": 0.6051},
+                       "entries": [{"rows": 8_000_000, "nq": 256, "h2d_GBps": 38.123, "rows_per_s": 7.4e7, "frac_of_pcie_peak": 0.6051, "overlap_hidden_frac": 0.93},
+                                   {"rows": 45_625_000, "nq": 1, "h2d_GBps": 37.0, "rows_per_s": 7.2e7, "frac_of_pcie_peak": 0.587, "overlap_hidden_frac": 0.9},
+                                   {"rows": 45_625_000, "nq": 256, "h2d_GBps": 36.5, "rows_per_s": 7.1e7, "frac_of_pcie_peak": 0.579, "overlap_hidden_frac": 0.95},
+                                   {"rows": 45_625_000, "skipped": "x"}]}
+    line = _check(bench.compact_line(doc, None))
+    st = line["more"]["streamed"]
+    assert st["bound"] == "pcie" and st["h2d_GBps"] == 38.1 and st["rows"] == 45_625_000 and st["nq"] == 256 and st["overlap_hidden_frac"] == 0.95
+
+
 def test_write_full_round_trips(tmp_path, monkeypatch):
     monkeypatch.setattr(bench, "REPO", str(tmp_path))
     doc = _doc()

@@ -112,6 +112,26 @@ def test_cli_search_and_easy_search_end_to_end(golden_dir, tmp_path):
     assert r.returncode != 0 and "MI355X" in (r.stderr + r.stdout)          # no CPU fallback
 
 
+def test_streamed_bench_block_on_a_small_memmap():
+    """bench.py's `streamed` block (the reference's db_iterator loop over a host memmap, dbsearch.py:233-243) on 300,000 rows in blocks of
+    65,536: the streamed search returns the bits of the same blocks scanned from HBM, and the entry carries rows/s, H2D GB/s against the
+    63 GB/s host link, the copy-only and scan-only legs and the overlap."""
+    import torch
+    sys.path.insert(0, REPO)
+    import bench
+    from merizo_search_amd import ops
+    from merizo_search_amd.foldclass import synthetic as syn
+    out = bench.streamed_bench(torch, ops, syn, torch.device("cuda", 0), 10, lambda m: None, sizes=(300_000,), nqs=(1, 96), block_rows=65_536)
+    assert out["bound"] == "pcie" and out["peak_GBps"] == 63.0
+    ents = [e for e in out["entries"] if "h2d_GBps" in e]
+    assert len(ents) == 2, out["entries"]
+    for e in ents:
+        assert e["identical_to_resident_blocks"] is True
+        assert 0.0 < e["frac_of_pcie_peak"] < 1.0 and e["rows_per_s"] > 1e6 and 0.0 <= e["overlap_hidden_frac"] <= 1.0
+        assert e["copy_only_seconds"] > 0 and e["scan_only_seconds"] > 0
+    assert len(out["block_sweep"]) == 3 and out["roofline"]["bound"] == "pcie" and out["roofline"]["frac"] == max(e["frac_of_pcie_peak"] for e in ents)
+
+
 def test_c_abi_from_plain_c(tmp_path):
     """The boundary is a C ABI: a plain-C program (tests/c_abi/abi_smoke.c, no Python or torch in the
     process) normalises, searches two shards, merges and checks against its own brute force."""

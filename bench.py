@@ -186,7 +186,7 @@ def measure_traffic_live(kernels, log, timeout_s=150):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="ms_pmc_")
         cmd = [rp, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", os.path.realpath(sys.executable), os.path.abspath(__file__),
-               "--no-extras", "--no-cpu-baseline", "--no-live-traffic", "--steps", "5", "--warmup", "3"]
+               "--no-extras", "--no-cpu-baseline", "--no-live-traffic", "--no-pipelined", "--steps", "5", "--warmup", "3"]
         env = {k_: v for k_, v in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         env["TMPDIR"] = tempfile.gettempdir()
         proc = subprocess.Popen(cmd, cwd=tempfile.gettempdir(), env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
@@ -892,6 +892,12 @@ def compact_line(doc, full_path=None):
             more["c3_search"]["prefiltered_ms_per_step"] = _r(c3["prefiltered"]["ms_per_step"])
     if doc.get("c3_end_to_end"):
         more["c3_end_to_end_domains_per_s"] = _r(doc["c3_end_to_end"]["domains_per_s"])
+    tw = doc.get("two_in_flight")
+    if tw:
+        more["two_in_flight"] = {"queries_per_s": _r(tw["queries_per_s"]), "ms_per_step": _r(tw["ms_per_step"]), "step_frac": _r(float("%.4g" % tw["step_frac"])),
+                                 "identical": tw.get("identical_to_one_in_flight")}
+        if tw.get("prefiltered"):
+            more["two_in_flight"]["prefiltered_queries_per_s"] = _r(tw["prefiltered"]["queries_per_s"])
     stv = doc.get("streamed")
     if stv and stv.get("roofline"):
         ents = [e for e in stv["entries"] if "h2d_GBps" in e]
@@ -1006,6 +1012,33 @@ def time_exchange(bench, reps=20):
     return float(t[0])
 
 
+def pipelined_rate(bench, steps, depth=2):
+    """Throughput with `depth` query batches in flight on `depth` HIP streams (each batch its own workspace, exchange block and outputs;
+    the database, its image and the raw queries shared): the small launches of batch i + 1 (query preparation, sample pass, bound) and the
+    merge of batch i - 1 run on the CUs the scan of batch i has not reached yet or has already left -- a serving loop's configuration.  NOT
+    the bench value: with launches of two batches interleaved, the HIP-event duration of a scan launch includes the time it queues behind
+    the other batch, so the top-level line (and its roofline) stays one batch in flight.  -> (ms per step, last results of every slot)."""
+    torch = bench.torch
+    dev = bench.db.device
+    slots = [bench] + [bench.variant(bench.prefilter) for _ in range(depth - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+    torch.cuda.synchronize()
+    for st_ in streams:
+        st_.wait_stream(torch.cuda.current_stream(dev))
+    res = [None] * depth
+    for i in range(4 * depth):
+        with torch.cuda.stream(streams[i % depth]):
+            res[i % depth] = slots[i % depth].step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        with torch.cuda.stream(streams[i % depth]):
+            res[i % depth] = slots[i % depth].step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return ms, res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1022,6 +1055,7 @@ def main():
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not measure roofline.traffic with rocprofv3 child passes (N = 1, default C2 shape, extras on: two passes of ~25 s); the "
                          "figure of the committed profile is used instead")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the `two_in_flight` block (N = 1: the same steps with two query batches in flight on two HIP streams)")
     ap.add_argument("--no-streamed", action="store_true", help="skip the `streamed` block (host memmap searched block by block over PCIe: writes up to 23.4 GB to /dev/shm)")
     ap.add_argument("--no-prefilter", action="store_true", help="skip the `prefiltered` blocks (the top-level line is the fp32 scan either way)")
     ap.add_argument("--exercise-exchange", action="store_true",
@@ -1128,6 +1162,25 @@ def main():
     c2 = (n_total, nq, k, world) == (1_000_000, 256, 10, 1)
     pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r05_pf_c2_pmc.json" if c2 else None) if use_pf else None
 
+    two = None
+    if world == 1 and nq > 64 and not args.no_pipelined:
+        # the same steps with two batches in flight (informative: see pipelined_rate)
+        ms2, r2 = pipelined_rate(bench, max(20, min(steps, 200)))
+        same = all(bool(torch.equal(r_[1], res[1]) and torch.equal(r_[0].view(torch.int32), res[0].view(torch.int32))) for r_ in r2)
+        two = {"depth": 2, "ms_per_step": ms2, "queries_per_s": nq / ms2 * 1e3, "identical_to_one_in_flight": same,
+               "step_frac": roofline(nq, bench.n_local, k, scan_ms, ms2)["step_frac"],
+               "note": "two query batches in flight on two HIP streams (own workspaces): the small launches of one batch fill the CUs the other's scan leaves idle in "
+                       "its ramp and tail; not the bench value (launch durations measured by events would include queueing)"}
+        if use_pf:
+            bp2 = bench.variant(True)
+            if bp2.prefilter:
+                msp2, rp2 = pipelined_rate(bp2, max(20, min(steps, 200)))
+                two["prefiltered"] = {"ms_per_step": msp2, "queries_per_s": nq / msp2 * 1e3,
+                                      "identical_to_fp32": all(bool(torch.equal(r_[1], res[1]) and torch.equal(r_[0].view(torch.int32), res[0].view(torch.int32))) for r_ in rp2)}
+            del bp2
+        if rank == 0:
+            print("[bench] two batches in flight: fp32 %.4f ms per step = %.0f q/s%s" % (ms2, nq / ms2 * 1e3,
+                  "; prefiltered %.4f ms = %.0f q/s" % (two["prefiltered"]["ms_per_step"], two["prefiltered"]["queries_per_s"]) if "prefiltered" in two else ""), file=sys.stderr, flush=True)
     if rank == 0:
         ms_per_step = elapsed / steps * 1e3
         roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
@@ -1161,6 +1214,7 @@ def main():
                                       "45.6M-row share; weak scaling holds queries/s constant while the database grows N-fold, so vs_ref is the scaling "
                                       "efficiency against this build's own one-rank point (`python bench.py --gpus 1 --shape c4` measures it alone)") if local_ref else None,
             "collective": collective,
+            "two_in_flight": two,
             "roofline": roof,
             "prefiltered": pf_main,
         }

@@ -76,16 +76,31 @@ static_assert(P_LAYER % 4 == 0 && P_W2F % 4 == 0 && P_WC % 4 == 0 && P_B1 % 4 ==
 // x = hi + mid + lo EXACTLY, each part a bf16 (the upper 16 bits of what is left: 8 + 8 + 8 significant bits).  A product x * w
 // over the parts has nine terms; hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid are kept -- what is dropped (mid.lo, lo.mid,
 // lo.lo) is below 2^-23 |x w|, the size of one fp32 rounding.  bf16 x bf16 products are exact in the fp32 accumulator.
+#ifndef MS_EGNN_SPLIT_PK
+#define MS_EGNN_SPLIT_PK 0          // round 6: packed residual subtractions in split3_pair -- 16 fewer vector instructions per block pair and 1.2 % SLOWER (three
+#endif                             // same-box passes: 57.7-57.8 against 57.0-57.1 ms per 1,000 domains, profiles/r06_egnn_split_pk_ab.log): not the default
 typedef __bf16 bf16x8_e __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4_e __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t &hi, uint32_t &mid, uint32_t &lo) {
     const uint32_t a = __float_as_uint(x0), b = __float_as_uint(x1);
     hi = __builtin_amdgcn_perm(b, a, 0x07060302u);                  // upper halves of x1 : x0
+#if MS_EGNN_SPLIT_PK
+    // Round 6 (VERDICT r05 #5a), measured and NOT the default: both residual subtractions of the pair as ONE packed fp32 instruction each
+    // (v_pk_add_f32 with the second operand negated) -- 9 vector instructions per pair instead of 11, the same bits (x - trunc(x) is exact
+    // either way), but the packed add wants its operands in aligned register pairs and issues no faster than two scalar ones here
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ r = f32x2_{x0, x1} - f32x2_{__uint_as_float(a & 0xFFFF0000u), __uint_as_float(b & 0xFFFF0000u)};
+    const uint32_t c = __float_as_uint(r.x), d = __float_as_uint(r.y);
+    mid = __builtin_amdgcn_perm(d, c, 0x07060302u);
+    const f32x2_ s = r - f32x2_{__uint_as_float(c & 0xFFFF0000u), __uint_as_float(d & 0xFFFF0000u)};
+    lo = __builtin_amdgcn_perm(__float_as_uint(s.y), __float_as_uint(s.x), 0x07060302u);
+#else
     const float r0 = x0 - __uint_as_float(a & 0xFFFF0000u), r1 = x1 - __uint_as_float(b & 0xFFFF0000u);
     const uint32_t c = __float_as_uint(r0), d = __float_as_uint(r1);
     mid = __builtin_amdgcn_perm(d, c, 0x07060302u);
     const float s0 = r0 - __uint_as_float(c & 0xFFFF0000u), s1 = r1 - __uint_as_float(d & 0xFFFF0000u);
     lo = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+#endif
 }
 
 __device__ __forceinline__ float silu_f(float x) {

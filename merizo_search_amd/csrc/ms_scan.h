@@ -54,6 +54,7 @@ struct ScanParams {
                             //      query tile in its set-up, APPROXIMATELY (q * (1 / max(|q|, eps)): a few ulp from F.normalize, far inside the scan's
                             //      error bound; the sample pass and the scan run the same sequence) -- the exact normalisation the answer needs is
                             //      done by the re-scoring launch, one query per workgroup (ms_rescore_body): no query-preparation launch at all
+    int debug_flags = 0;    // diagnostics (MS_PF_DEBUG, fp16-image scan): 1 = every threshold +inf (the rare path is compiled in and never taken: WRONG results)
     int unit_rows;          // MS_MODE_COSINE_UNIT: the rows are L2-normalised already (no inv_norm array); lengths / qlen mask as usual
     const float *ub_s;      // [nq_pad] exclusive upper bound of this pass (total order), or NULL
     const uint32_t *ub_i;

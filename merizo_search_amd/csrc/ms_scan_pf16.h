@@ -38,8 +38,30 @@ constexpr uint32_t MS_PF16_MAGIC = 0x3631464du;       // "MF16"
 #ifndef MS_PF16_SHADOW
 #define MS_PF16_SHADOW 0
 #endif
+#ifdef MS_PF16_HALF_LDS          // (diagnostic build, WRONG results: only half of a tile's fragments are read from LDS -- what do the LDS reads cost?)
+#define MS_PF16_SECOND_READ(B)
+#else
+#define MS_PF16_SECOND_READ(B) fr[2 * (B) + 1] = src[64 * (2 * (B) + 1)];
+#endif
+// Round 6 (MS_PF16_DYNPRIO, default on): the wave that finds its next tile complete on arrival -- the one the workgroup is waiting for, e.g.
+// after a visit of the rare path -- takes the higher issue priority for its next chain, a wave that has to wait the lower one: -2 to -2.5 % on
+// long streams in two interleaved same-box passes (16M x 1024: 3.48 -> 3.40 ms; 4M x 256: 0.252 -> 0.246 ms), C2 unchanged
+// (profiles/r06_pf16_dynprio_ab.log)
+#ifndef MS_PF16_DYNPRIO
+#define MS_PF16_DYNPRIO 1
+#endif
+#if MS_PF16_DYNPRIO
+#define MS_PF16_PRIO_BEHIND "s_setprio 2\n\t"
+#define MS_PF16_PRIO_AHEAD "s_setprio 0\n\t"
+#else
+#define MS_PF16_PRIO_BEHIND
+#define MS_PF16_PRIO_AHEAD
+#endif
 #ifndef MS_PF16_HIST_PERIOD
 #define MS_PF16_HIST_PERIOD MS_HIST_PERIOD     // tiles between two looks at the shared bound in this kernel (8 needs MS_PF2_HIST_AREAS = 8)
+#endif
+#ifndef MS_PF16_VISIT2
+#define MS_PF16_VISIT2 1           // the rare path as straight-line predicated code (0: the ballot-and-select-tree form of rounds 4-5)
 #endif
 #ifndef MS_PF16_GROUPED
 #define MS_PF16_GROUPED 1          // the rare path looks for candidates group of four registers by group (0: sixteen ballots, rounds 4-5)
@@ -171,7 +193,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         asm volatile("s_waitcnt lgkmcnt(0)\n\t"
                      "v_readfirstlane_b32 %0, %2\n\t"
                      "s_cmp_ge_u32 %0, %5\n\t"
+                     MS_PF16_PRIO_BEHIND                   // (nothing to wait for: this wave is the one the others wait for)
                      "s_cbranch_scc1 2f\n\t"
+                     MS_PF16_PRIO_AHEAD                    // (it has to wait: it is ahead)
                      "s_and_b32 %0, %4, 15\n\t"           // (the counter's address: only needed on this path)
                      "s_lshl_b32 %0, %0, 2\n\t"
                      "s_add_u32 %0, %0, %6\n\t"
@@ -258,6 +282,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         st.tau = st.floor;
     }
     if (!q_valid) { st.floor = INFINITY; st.tau = INFINITY; }   // padding queries never pass the filter
+    if (!SAMPLE && (p.debug_flags & 1)) { st.floor = INFINITY; st.tau = INFINITY; }      // (diagnostics: nothing ever passes)
     hg.counters = nullptr; hg.base = 0.0f; hg.step = 0.0f; hg.inv_step = 0.0f;
     if (hist_on && q_valid) {
         const float stp = pre_stp, lb = pre_lb;
@@ -380,7 +405,57 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         ccnt = 0;
         retau();
     };
-    auto visit = [&](f32x16 &sc_v, int t, int half, bool check_rows) __attribute__((always_inline)) {
+    // Round 6: the rare path as straight-line predicated code.  The form below it (rounds 4-5) finds the candidate registers with a chain of
+    // ballots, then loops over them with a uniform index and a 15-select tree: ~130 instructions of which most are scalar-after-vector
+    // dependencies (v_cmp -> s_cmp -> s_cselect -> s_or ...), 1,400 cycles per visit -- and a visit of ANY of the eight waves delays the whole
+    // workgroup (no wave has spare speed to catch up: the diagnostic build without visits runs 19-27 % faster, profiles/r06_pf16_diag_*).
+    // Here: group maxima (8 instructions), one test per group of four registers, and per register of a hit group `v_cmp; s_and_saveexec;
+    // s_cbranch_execz` around a body that runs for the passing lanes only (count in the histogram, append, mark the register taken).  A lane
+    // whose buffer is full does not append: it raises `ovf`, the buffers are flushed into the lists and the tile is visited again -- the
+    // registers already taken are -inf by then (the accumulators are dead after the visit: the next chain zeroes them).
+    // Measured (profiles/r06_pf16_visit2_ab.log): k = 10 shapes unchanged (the visits that actually run cost 8 % of the C2 launch and 2 % of
+    // a long stream: MS_PF_DEBUG=1), k = 32 (16-entry lists) 6 % faster.  The cosine + mask instantiations with the query split hi / lo or with
+    // 16-entry lists spill 330-1,250 bytes per lane around this form and keep the older one.
+    constexpr bool VISIT2 = MS_PF16_VISIT2 && !(MASK && (NQP == 2 || KL >= 16));
+    auto visit_v2 = [&](f32x16 &sc_v, int t, int half, bool check_rows) __attribute__((always_inline)) {
+        if (mask_on) apply_mask(sc_v, t, half);
+        const uint32_t sub_row0 = (uint32_t)(row_begin + (int64_t)t * 64) + (uint32_t)(32 * half + 4 * h);
+#pragma unroll 1
+        for (;;) {
+            bool ovf = false;
+            float g0, g1, g2, g3;
+            asm("v_max3_f32 %0, %4, %5, %6\n\tv_max3_f32 %1, %8, %9, %10\n\tv_max3_f32 %2, %12, %13, %14\n\tv_max3_f32 %3, %16, %17, %18\n\t"
+                "v_max_f32 %0, %0, %7\n\tv_max_f32 %1, %1, %11\n\tv_max_f32 %2, %2, %15\n\tv_max_f32 %3, %3, %19"
+                : "=&v"(g0), "=&v"(g1), "=&v"(g2), "=&v"(g3)
+                : "v"(sc_v[0]), "v"(sc_v[1]), "v"(sc_v[2]), "v"(sc_v[3]), "v"(sc_v[4]), "v"(sc_v[5]), "v"(sc_v[6]), "v"(sc_v[7]), "v"(sc_v[8]),
+                  "v"(sc_v[9]), "v"(sc_v[10]), "v"(sc_v[11]), "v"(sc_v[12]), "v"(sc_v[13]), "v"(sc_v[14]), "v"(sc_v[15]));
+#define MS_PF16_REG(I)                                                                                                   \
+            {                                                                                                            \
+                const float ss = sc_v[I];                                                                                \
+                const uint32_t row = sub_row0 + (uint32_t)(8 * ((I) >> 2) + ((I) & 3));                                    \
+                bool pass = ss > tau_s;                                                                                  \
+                if (check_rows) pass = pass && ((int64_t)row < row_end);                                                 \
+                if (pass) {                                                                                              \
+                    if (ccnt < (uint32_t)PF2_CAND) {                                                                     \
+                        const float s_ = ss * down;                      /* the approximate score itself (exact: a power of two) */ \
+                        if (hg.counters != nullptr) ms_hist_count(hg, s_);                                               \
+                        *cand_slot(ccnt) = ms_u32x2{__float_as_uint(s_), row};                                           \
+                        ccnt += 1;                                                                                       \
+                        sc_v[I] = -INFINITY;                                                                             \
+                    } else {                                                                                             \
+                        ovf = true;                                                                                      \
+                    }                                                                                                    \
+                }                                                                                                        \
+            }
+#define MS_PF16_GROUP(G, GM) if (__ballot(GM > tau_s) != 0) { MS_PF16_REG(4 * (G)) MS_PF16_REG(4 * (G) + 1) MS_PF16_REG(4 * (G) + 2) MS_PF16_REG(4 * (G) + 3) }
+            MS_PF16_GROUP(0, g0) MS_PF16_GROUP(1, g1) MS_PF16_GROUP(2, g2) MS_PF16_GROUP(3, g3)
+#undef MS_PF16_GROUP
+#undef MS_PF16_REG
+            if (__builtin_expect(__ballot(ovf) == 0, 1)) break;
+            flush();                                        // some lane's buffer was full: the lists take the buffers, then the rest of the tile
+        }
+    };
+    auto visit_v1 = [&](f32x16 &sc_v, int t, int half, bool check_rows) __attribute__((always_inline)) {
         if (mask_on) apply_mask(sc_v, t, half);
         const uint32_t sub_row0 = (uint32_t)(row_begin + (int64_t)t * 64) + (uint32_t)(32 * half + 4 * h);
         uint32_t regs = 0;                                   // registers holding a candidate of some lane (uniform)
@@ -433,6 +508,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             }
             if (__builtin_expect(__ballot(ccnt >= PF2_CAND) != 0, 0)) flush();     // some lane's buffer is full
         }
+    };
+    auto visit = [&](f32x16 &sc_v, int t, int half, bool check_rows) __attribute__((always_inline)) {
+        if constexpr (VISIT2) visit_v2(sc_v, t, half, check_rows); else visit_v1(sc_v, t, half, check_rows);
     };
 
 #ifdef MS_STAMP
@@ -525,7 +603,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             }                                                                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                                        \
             fr[2 * (B)] = src[64 * (2 * (B))];                                                                        \
-            fr[2 * (B) + 1] = src[64 * (2 * (B) + 1)];                                                                \
+            MS_PF16_SECOND_READ(B)                                                                                    \
         }
         MS_PF2_BLOCK(0)
         __builtin_amdgcn_sched_barrier(0);
@@ -628,6 +706,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             }
         };
         int t = 0;
+#if !MS_PF16_SHADOW
+        // ONE stage per iteration (round 6: two per iteration doubled every copy of the rare path in the instruction cache; the register swap
+        // that needed pairs belongs to the shadow form): the body of a stream -- every stage issues (t + D < ntl) -- ...
+        for (; t + PF2_D < ntl; ++t) {
+            if ((t & 1) == 0) {
+                if (pace_on) pace(t);
+                if (hist_on) hist_step(t);
+            }
+            stage(std::true_type{}, t, accA0, accA1, accA0, accA1);
+        }
+        // ... and its last D tiles, with the tests in
+        for (; t < ntl; ++t) {
+            if ((t & 1) == 0 && hist_on) hist_step(t);
+            stage(std::false_type{}, t, accA0, accA1, accA0, accA1);
+        }
+#else
         // the body of a stream: every stage issues (t + 1 + D < ntl), two tiles per iteration ...
         for (; t + 1 + PF2_D < ntl; t += 2) {
             if (pace_on) pace(t);
@@ -659,6 +753,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
                 stage(std::false_type{}, t, accA0, accA1, accA0, accA1);
             }
         }
+#endif
 #ifdef MS_STAMP
         if (!SAMPLE && lane == 0 && p.stamps != nullptr && (size_t)bid * 64 + 64 <= 4 * 4 * 65536) {
             unsigned long long *o = p.stamps + ((size_t)bid * 8 + wave) * 8;

@@ -1397,6 +1397,10 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
     }
     if ((stages & 1) && (stages & 2) && sp.hist != nullptr) (void)hist_take_clean(workspace, n, nq, L.kp);
     sp.k = pl.k_pass;
+    {
+        static const int dbg = [] { const char *e = getenv("MS_PF_DEBUG"); return e ? atoi(e) : 0; }();
+        sp.debug_flags = dbg;
+    }
     if (stages & 2) {
         if (image != nullptr && format != MS_PF_BF16X3 && pl.n_qgroups >= 2 && pl.n_qgroups <= 16 && pace_setting()) {
             // several query groups walk every row stream: they pace each other through progress words (ms_scan_pf16.h) so that a tile

@@ -329,44 +329,102 @@ class HipEngine:
         side.synchronize()
         return out
 
-    def device_blocks(self, blocks):
-        """Out-of-core streaming (the reference's db_iterator loop, dbsearch.py:233-243): yields each host
-        block as a device tensor.  Double-buffered: while the consumer's scan of block b runs, block
-        b+1 is read into pinned memory and copied on a side stream; a device buffer is overwritten only
-        after the work the consumer enqueued on it has finished (event recorded when the consumer asks
-        for the next block)."""
+    STREAM_SLOTS = 3
+
+    def _stream_buffers(self, slot: int, rows: int):
+        """Pinned + device staging buffer number `slot` of the streamed search, at least `rows` rows: allocated ONCE per engine and reused by
+        every later call (round 6: pinning two fresh 128 MiB buffers per call was half of an 8M-row search: 19 -> 33 GB/s)."""
         torch = self.torch
-        side = torch.cuda.Stream(device=self.device)
+        st = getattr(self, "_stream_state", None)
+        if st is None:
+            st = self._stream_state = {"pinned": [None] * self.STREAM_SLOTS, "dev": [None] * self.STREAM_SLOTS,
+                                       "side": torch.cuda.Stream(device=self.device)}
+        if st["pinned"][slot] is None or st["pinned"][slot].shape[0] < rows:
+            st["pinned"][slot] = torch.empty((rows, W.DIM), dtype=torch.float32).pin_memory()
+            with torch.cuda.device(self.device):
+                st["dev"][slot] = torch.empty((rows, W.DIM), dtype=torch.float32, device=self.device)
+            return st["pinned"][slot], st["dev"][slot], True
+        return st["pinned"][slot], st["dev"][slot], False
+
+    def device_blocks(self, blocks):
+        """Out-of-core streaming (the reference's db_iterator loop, dbsearch.py:233-243): yields each host block as a device
+        tensor.  Three staging slots filled by a BACKGROUND thread (round 6): while the consumer enqueues and runs its scan of block b,
+        the thread reads block b + 1 (b + 2) into pinned memory (the host copy releases the GIL) and copies it on a side stream; a device
+        buffer is overwritten only after the work the consumer enqueued on it has finished (an event recorded when the consumer asks for
+        the next block).  Before: the consumer's own host-side work per block (launches, the running merge) and the host copy of the next
+        block took turns on one thread."""
+        import queue
+        import threading
+        torch = self.torch
         main = torch.cuda.current_stream(self.device)
-        pinned, dev, copied, used = [None, None], [None, None], [None, None], [None, None]
+        self._stream_buffers(0, 1)                              # (creates the state)
+        st = self._stream_state
+        side = st["side"]
+        side.wait_stream(main)                                  # the buffers' previous users (an earlier call's scans) are on the main stream
+        ready = queue.Queue(maxsize=self.STREAM_SLOTS - 1)      # staged blocks: (slot, rows, copied event) | None (end) | an exception
+        free = queue.Queue()                                    # slots handed back: (slot, event after which its device buffer may be overwritten)
+        for s_ in range(self.STREAM_SLOTS):
+            free.put((s_, None))
+        stop = threading.Event()
+        copied = [None] * self.STREAM_SLOTS
 
-        def stage(slot, block):
-            rows = block.shape[0]
-            if isinstance(block, torch.Tensor):
-                block = block.numpy()
-            if pinned[slot] is None or pinned[slot].shape[0] < rows:
-                pinned[slot] = torch.empty((rows, W.DIM), dtype=torch.float32).pin_memory()
-                dev[slot] = torch.empty((rows, W.DIM), dtype=torch.float32, device=self.device)
-                side.wait_stream(main)                      # a fresh buffer may reuse memory the main stream is still reading
-            if copied[slot] is not None:
-                copied[slot].synchronize()
-            self._host_copy(pinned[slot][:rows].numpy(), block)
-            with torch.cuda.stream(side):
-                if used[slot] is not None:
-                    side.wait_event(used[slot])
-                dev[slot][:rows].copy_(pinned[slot][:rows], non_blocking=True)
-                copied[slot] = side.record_event()
-            return rows
+        def put_ready(item) -> bool:
+            while not stop.is_set():
+                try:
+                    ready.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    continue
+            return False
 
-        it = iter(blocks)
-        nxt = next(it, None)
-        slot = 0
-        rows = stage(slot, nxt) if nxt is not None else 0
-        while nxt is not None:
-            main.wait_event(copied[slot])
-            yield dev[slot][:rows]                          # the consumer enqueues its scan of this block ...
-            used[slot] = main.record_event()
-            nxt = next(it, None)
-            if nxt is not None:                             # ... and the next block is read + copied meanwhile
-                slot ^= 1
-                rows = stage(slot, nxt)
+        def worker():
+            try:
+                torch.cuda.set_device(self.device)
+                for block in blocks:
+                    if isinstance(block, torch.Tensor):
+                        block = block.numpy()
+                    rows = block.shape[0]
+                    if rows == 0:
+                        continue
+                    slot = None
+                    while not stop.is_set():
+                        try:
+                            slot, used = free.get(timeout=0.05)
+                            break
+                        except queue.Empty:
+                            continue
+                    if slot is None:
+                        return
+                    pinned, dev, fresh = self._stream_buffers(slot, rows)
+                    if copied[slot] is not None:
+                        copied[slot].synchronize()              # the previous copy out of this pinned buffer has left it
+                    self._host_copy(pinned[:rows].numpy(), block)
+                    with torch.cuda.stream(side):
+                        if fresh:
+                            side.wait_stream(main)              # a fresh buffer may reuse memory the main stream is still reading
+                        if used is not None:
+                            side.wait_event(used)
+                        dev[:rows].copy_(pinned[:rows], non_blocking=True)
+                        copied[slot] = side.record_event()
+                    if not put_ready((slot, rows, copied[slot])):
+                        return
+                put_ready(None)
+            except BaseException as exc:                        # (reported to the consumer, which re-raises it)
+                put_ready(exc)
+
+        th = threading.Thread(target=worker, name="merizo-stream-stage", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = ready.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                slot, rows, ev = item
+                main.wait_event(ev)
+                yield st["dev"][slot][:rows]                    # the consumer enqueues its scan of this block ...
+                free.put((slot, main.record_event()))           # ... and the slot goes back once that work has been enqueued
+        finally:
+            stop.set()
+            th.join(timeout=30.0)

@@ -68,6 +68,7 @@ struct ScanParams {
     int64_t *fin_i;
     int64_t fin_row_offset;
     int fin_stride;
+    const int *fin_qmap = nullptr;   // ... of query q of the batch into output row fin_qmap[q] (the exact pass behind a prefiltered search of a handful of queries)
     int prefilter = 0;      // loader-wave form only: score with three bf16 matrix instructions on the split operands (approximate scores;
                             // the caller re-scores the survivors exactly: ms_ip_topk_prefiltered)
     const ScanDevPlan *dev_plan = nullptr;   // ms_scan_kernel only: nq, the streams and the grid come from device memory (exact pass
@@ -940,13 +941,14 @@ __device__ __forceinline__ void ms_scan_body(const ScanParams &p_in) {
                 __syncthreads();
                 MS_BODY_STAMP(7);
                 const uint2 *fin = ms_block_merge(ent, smem, p.P, p.k, tid);
+                const int q_out = p.fin_qmap != nullptr ? p.fin_qmap[q_first + q0] : q_first + q0;      // (uniform)
                 if (fin == nullptr) {        // (uniform across the workgroup) the shapes it declines: head-advance merge by one wave
                     if (wave == 0)
                         ms_head_merge_wave<4, true>(ent, p.part_s, p.part_i, p.P, p.k, p.fin_row_offset, p.fin_s, p.fin_i, p.fin_stride, 0,
-                                                    nullptr, nullptr, q_first + q0, lane);
+                                                    nullptr, nullptr, q_out, lane);
                 } else if (tid < p.k) {
                     const uint2 v = fin[tid];
-                    const size_t o = (size_t)(q_first + q0) * p.fin_stride + tid;
+                    const size_t o = (size_t)q_out * p.fin_stride + tid;
                     p.fin_s[o] = __uint_as_float(v.x);
                     p.fin_i[o] = v.y == MS_IDX_NONE ? (int64_t)-1 : p.fin_row_offset + (int64_t)v.y;
                 }

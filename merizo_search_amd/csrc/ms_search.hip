@@ -1007,7 +1007,7 @@ void fill_scan_params(const ScanPlan &pl, const float *db, int64_t n, const floa
     sp->unit_rows = mode == MS_MODE_COSINE_UNIT ? 1 : 0;
     sp->ub_s = nullptr; sp->ub_i = nullptr; sp->lb_s = nullptr; sp->max_tiles = 0;
     sp->hist = nullptr; sp->hstep = nullptr;
-    sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr;
+    sp->fin_s = nullptr; sp->fin_i = nullptr; sp->fin_row_offset = 0; sp->fin_stride = 0; sp->ticket = nullptr; sp->fin_qmap = nullptr;
     sp->prefilter = 0; sp->gate = nullptr; sp->gate_epoch = 0; sp->pf_image = nullptr; sp->pf_format = 0; sp->qpw = pl.qpw;
     sp->list_sm = pl.list_sm; sp->prog = nullptr; sp->prog_epoch = 0;
     sp->part_s = reinterpret_cast<float *>(ws + pl.off_part_s);
@@ -1458,10 +1458,21 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         pg.grid = L.exact_grid_max; pg.P = L.exact_P_max; pg.qwb = 1;     // (qwb = 1: routes to ms_scan_kernel, whose decomposition is the device plan's)
         sx.qwb = 1;
         sx.list_sm = 0;                      // (ms_scan_kernel writes rank-major lists)
+        // A handful of queries (the reference's own CLI regime over the fp16 image of a large database; round 6): the exact pass merges
+        // inside its own launch -- the last workgroup of the query group, as ms_ip_topk does for such batches -- so that ONE gated launch
+        // follows the re-scoring instead of two (each costs ~5 us even when it returns at once).  More queries: the last workgroup would
+        // merge them one after the other (4.4 us each) while 255 others have finished; the merge launch stays.
+        const bool fuse_exact = nq <= fused_merge_setting() && L.exact_P_max <= 256 && (size_t)px.k_pass * L.exact_P_max <= 4224;
+        if (fuse_exact) {
+            sx.fin_s = out_scores; sx.fin_i = out_idx; sx.fin_row_offset = row_offset; sx.fin_stride = k; sx.fin_qmap = qmap;
+            sx.ticket = reinterpret_cast<uint32_t *>(blk);
+        }
         rc = launch_scan(pg, sx, st);
         if (rc) return rc;
-        rc = launch_merge(pg, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st, dp, qmap);
-        if (rc) return rc;
+        if (!fuse_exact) {
+            rc = launch_merge(pg, sx, nq, px.k_pass, row_offset, out_scores, out_idx, k, 0, nullptr, nullptr, st, dp, qmap);
+            if (rc) return rc;
+        }
     }
     return MS_OK;
 }

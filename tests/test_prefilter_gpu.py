@@ -533,6 +533,29 @@ def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, t
     _check(torch, ops, orc, db, q, k, 1.0 + 1e-6, row_offset=9, raw=(nq % 2 == 1), expect_fallback=False, image=image)
 
 
+@pytest.mark.parametrize("image", ["f16x2", "f16x1"])
+@pytest.mark.parametrize("nq,k,flag", [(1, 10, 1), (3, 10, 3), (8, 5, 4), (8, 16, 8), (9, 10, 9)])
+def test_few_flagged_queries_merge_inside_the_gated_exact_scan(nq, k, flag, image, torch_gpu):
+    """Round 6: for a handful of queries (<= the fused-merge threshold: 2 in production, 8 in this suite) over the fp16 image of a large
+    database the exact pass behind the prefilter is ONE gated launch -- its last workgroup merges the flagged queries' lists and scatters
+    them into their output rows -- instead of a scan and a merge launch.  `flag` of the nq queries own a family of 60 rows within ~1e-6 of
+    each other (no proof possible: exactly they take the exact pass); 9 queries: the two-launch form.  Indices and score bits == the oracle,
+    raw and prepared queries."""
+    torch = torch_gpu
+    from merizo_search_amd import ops
+    from oracle import oracle as orc
+    n = 1_050_000
+    rng = np.random.default_rng(900 + nq + k)
+    db, q = _norm_db(n, seed=581), _norm_db(nq, seed=582 + nq)
+    owners = list(range(0, nq, max(1, nq // flag)))[:flag]
+    for j, o in enumerate(owners):
+        fam = q[o][None, :] + rng.standard_normal((60, 128)).astype(np.float32) * 2e-7
+        fam /= np.linalg.norm(fam, axis=1, keepdims=True)
+        db[(np.arange(60) * 15_013 + 1_000 * j + 7) % n] = fam.astype(np.float32)
+    for raw in (False, True):
+        _check(torch, ops, orc, db, (q * np.float32(3.0)) if raw else q, k, 1.0 + 1e-6, row_offset=5, raw=raw, expect_flagged=len(owners), image=image)
+
+
 def test_engine_builds_the_image_for_few_query_searches_from_the_third_call(torch_gpu):
     """foldclass/engine.py: a resident database of >= ms_pf_few_min_rows() rows searched with a handful of queries per call (the CLI's
     loop over query structures) gets its fp16 image at the third such search -- one pass over the rows -- and every later search

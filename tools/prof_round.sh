@@ -4,7 +4,7 @@
 # under gpurun_out/<tag>prof/ and are copied into profiles/ from there.
 #   usage: bash tools/prof_round.sh TAG [part ...]     parts: pf c2 c4 c3 hbm k64 egnn   (default: all)
 set -u
-TAG=${1:-r05}; shift || true
+TAG=${1:-r06}; shift || true
 PARTS=${*:-"pf c2 c4 c3 hbm k64 egnn"}
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${TAG}prof
@@ -25,7 +25,8 @@ if has pf; then
   pmc pf_c2_write WRITE_SIZE $R/tools/pf_loop.py 1000000 256 10 5
   pmc pf_c2_busy "$BUSY" $R/tools/pf_loop.py 1000000 256 10 5
   tojson $OUT/${TAG}_pf_c2_pmc.json "$PFK" "tools/pf_loop.py 1000000 256 10 5 (C2, prefiltered search over the fp16 image: 1,000,000 x 128 rows, 256 queries, top-10)" 256000000 65536000000 /tmp/pmc_pf_c2_fetch /tmp/pmc_pf_c2_write /tmp/pmc_pf_c2_busy
-  kt pf_c4 $R/tools/pf_loop.py 45625000 4096 10 2
+  # (MS_PF_FORMAT=f16x1: no search of 256 of the database's own rows to choose the arithmetic -- its launches of the same kernel name polluted round 5's average)
+  MS_PF_FORMAT=f16x1 kt pf_c4 $R/tools/pf_loop.py 45625000 4096 10 3
   pmc pf_c4_busy "$BUSY" $R/tools/pf_loop.py 45625000 4096 10 1
   pmc pf_c4_fetch FETCH_SIZE $R/tools/pf_loop.py 45625000 4096 10 1          # (4 launches: 3 warm-up + 1 -- every one is a pass over the shard)
   pmc pf_c4_write WRITE_SIZE $R/tools/pf_loop.py 45625000 4096 10 1
@@ -49,11 +50,11 @@ PY
   tojson $OUT/${TAG}_pf_c3_pmc.json "$PFKM" "tools/prof_c3.py 5 prefiltered (c3_search: 500,000 unit rows + lengths, 1000 queries, mincov 0.7, top-10)" 130000000 128000000000 /tmp/pmc_pf_c3_fetch /tmp/pmc_pf_c3_write /tmp/pmc_pf_c3_busy
 fi
 if has c2; then   # C2: the bench's top-level step (fp32 scan)
-  kt c2 $R/bench.py --no-extras --no-cpu-baseline --no-prefilter
-  pmc c2_fetch FETCH_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
-  pmc c2_write WRITE_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
-  pmc c2_busy "$BUSY" $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3
-  tojson $OUT/${TAG}_c2_pmc.json "ms_scan_loader_kernel<5, 0, false, false>" "bench.py --no-extras --no-cpu-baseline --no-prefilter --steps 5 --warmup 3 (C2: 1,000,000 x 128 rows, 256 queries, top-10, fp32 scan)" 512000000 65536000000 /tmp/pmc_c2_fetch /tmp/pmc_c2_write /tmp/pmc_c2_busy
+  kt c2 $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --no-pipelined --no-live-traffic
+  pmc c2_fetch FETCH_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --no-pipelined --no-live-traffic --steps 5 --warmup 3
+  pmc c2_write WRITE_SIZE $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --no-pipelined --no-live-traffic --steps 5 --warmup 3
+  pmc c2_busy "$BUSY" $R/bench.py --no-extras --no-cpu-baseline --no-prefilter --no-pipelined --no-live-traffic --steps 5 --warmup 3
+  tojson $OUT/${TAG}_c2_pmc.json "ms_scan_loader_kernel<5, 0, false, false>" "bench.py --no-extras --no-cpu-baseline --no-prefilter --no-pipelined --no-live-traffic --steps 5 --warmup 3 (C2: 1,000,000 x 128 rows, 256 queries, top-10, fp32 scan)" 512000000 65536000000 /tmp/pmc_c2_fetch /tmp/pmc_c2_write /tmp/pmc_c2_busy
 fi
 if has c4; then   # one rank's share of C4 (fp32 scan)
   kt c4 $R/tools/prof_scan.py 45625000 4096 10 2

@@ -56,11 +56,15 @@ for c in range(ncases):
         db = db * sc; bound *= sc
         if not raw:
             q = q * float(2.0 ** rng.integers(-25, 25))
+    if os.environ.get("MS_STRESS_VERBOSE"):
+        print("case", c, dict(n=n, nq=nq, k=k, kind=kind, raw=raw, mode=mode, image=fmt_name if use_image else None, kw=sorted(kw)), flush=True)
     img = ops.pf_build_image(db, fmt=FMT[fmt_name], row_norm_bound=bound) if use_image else None
     s0, i0 = ops.ip_topk(db, q, k, mode=mode, row_offset=off, **kw)
     ws = ops.PrefilterWorkspace(db.device).get(n, nq, k)
     s1, i1 = ops.ip_topk_prefiltered(db, q, k, bound, mode=mode, row_offset=off, workspace=ws, image=img, **kw)
     fl = ops.prefilter_flagged(ws)
+    if os.environ.get("MS_STRESS_VERBOSE"):
+        print("   ok, flagged", fl, flush=True)
     if use_image and mode != ops.MODE_COSINE_UNIT and ops.prefilter_serves(n, nq, k):
         # the approximation itself: the candidate lists the scan left in the workspace against float64
         a_s = np.zeros((nq, 64), np.float32); a_i = np.zeros((nq, 64), np.int64); kp = ctypes.c_int(0)

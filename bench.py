@@ -7,9 +7,9 @@
 
 N = 1 (default): BASELINE.json configs[1] (C2) -- brute-force cosine top-10 over a 1M x 128 float32
 synthetic database, batch = 256 queries.  A step is one pass of the hot path over one query batch:
-raw query embeddings -> ms_l2_normalize_rows_to -> sample pass -> fused Q.D^T + top-k scan of the
-resident shard -> merge of the per-stream lists [-> RCCL all-gather of the per-shard top-k + shard
-merge when N > 1].  The database and the raw query embeddings are resident in HBM before the timed
+raw query embeddings -> F.normalize INSIDE the calls (MS_MODE_IP_NORMQ, as the driver makes them) -> sample
+pass -> fused Q.D^T + top-k scan of the resident shard -> merge of the per-stream lists [-> RCCL all-gather
+of the per-shard top-k + shard merge when N > 1].  The database and the raw query embeddings are resident in HBM before the timed
 region starts.
 
 N > 1: the TED shape of BASELINE.json configs[3] (C4), weak scaling -- every rank generates and holds
@@ -37,9 +37,12 @@ goes to bench_full.json beside this file and to stderr.  The blocks:
                 corrections applied (`--no-live-traffic`, or no rocprofv3: the figure of the committed PMC passes under profiles/, and
                 `traffic_from` says which); the other blocks carry the committed profiles' figures (`traffic_source`);
   prefiltered   (N = 1) the same step through the prefiltered search: ms per step, q/s, identical_to_fp32, how many queries needed
-                the exact pass, and the roofs of ITS scan launch (ms_scan_pf2_kernel): the algorithmic flops UN-tripled, the
-                flops it executes (3 bf16 matrix instructions per 16 dimensions) against the dense bf16 matrix peak, the bytes of
-                the image (512 B per row) against the HBM peak;
+                the exact pass, and the roofs of ITS scan launch (ms_scan_pf16_kernel): the flops it executes (m 16-bit matrix
+                instructions per 16 dimensions) against the dense 16-bit matrix peak, the bytes of the image (256 B per row)
+                against the HBM peak;
+  two_in_flight (N = 1, informative) the same steps with two query batches in flight on two HIP streams;
+  streamed      (N = 1) the reference's db_iterator loop: a host memmap searched block by block over PCIe (bound: 63 GB/s);
+  collective    (N > 1) backend, ranks, DISTINCT devices (PCI bus ids), RCCL version, the exchange's own time;
   clustered     (N = 1) C2 with 64 of the 256 queries owning a family of 200 near-duplicate rows (within 1e-6 of each other): the
                 prefilter cannot prove those 64 answers and gives exactly them an exact pass; both paths timed;
   cpu_baseline  the CPU oracle (oracle/oracle.c: AVX2 + OpenMP port of the faiss path) on this host's
@@ -530,7 +533,7 @@ def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
            "roofline": roofline(nq, n, k, scan_ms, ms)}
     out["roofline"]["kernel"] = "ms_scan_loader_kernel<5, 2> (unit-row cosine variant: in-chain filter on the final scores, length mask in the rare path)"
     out["roofline"]["algorithmic_bytes_per_launch"] = 516.0 * n          # rows + their lengths
-    attach_committed_traffic(out["roofline"], "r05_c3_pmc.json")
+    attach_committed_traffic(out["roofline"], "r06_c3_pmc.json")
     log("c3_search: %.3f ms per 1000-query batch (scan %.3f ms = %.1f%% of fp32 MFMA peak), score error %.1e" % (ms, scan_ms, out["roofline"]["frac"] * 100, err))
     state = {"unit": unit, "lengths": lengths, "mincov": mincov, "n": n, "k": k, "image": None, "pws": None}
     if prefilter and ops.prefilter_serves(n, nq, k):
@@ -554,7 +557,7 @@ def c3_search_bench(torch, ops, syn, dev, k, log, prefilter=True):
         out["prefiltered"] = {"ms_per_step": pms, "queries_per_s": nq / pms * 1e3, "dtype": PF_FORMATS[pf_format_name(ops, img)][3],
                               "identical_to_fp32": bool(torch.equal(pi, out_i) and torch.equal(ps.view(torch.int32), out_s.view(torch.int32))),
                               "exact_pass_queries": ops.prefilter_flagged(pws), "roofline": roofline(nq, n, k, pscan, pms, prefiltered=pf_format_name(ops, img))}
-        attach_committed_traffic(out["prefiltered"]["roofline"], "r05_pf_c3_pmc.json")
+        attach_committed_traffic(out["prefiltered"]["roofline"], "r06_pf_c3_pmc.json")
         log("c3_search prefiltered: %.3f ms per batch (scan %.3f ms), identical: %s, exact-pass queries: %d" % (
             pms, pscan, out["prefiltered"]["identical_to_fp32"], out["prefiltered"]["exact_pass_queries"]))
         state.update(image=img, pws=pws)
@@ -1160,7 +1163,7 @@ def main():
         return blk
 
     c2 = (n_total, nq, k, world) == (1_000_000, 256, 10, 1)
-    pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r05_pf_c2_pmc.json" if c2 else None) if use_pf else None
+    pf_main = pf_block(bench, res, max(20, min(steps, 200)), 10, pmc="r06_pf_c2_pmc.json" if c2 else None) if use_pf else None
 
     two = None
     if world == 1 and nq > 64 and not args.no_pipelined:
@@ -1185,7 +1188,7 @@ def main():
         ms_per_step = elapsed / steps * 1e3
         roof = roofline(nq, bench.n_local, k, scan_ms, ms_per_step)
         if c2:
-            attach_committed_traffic(roof, "r05_c2_pmc.json")
+            attach_committed_traffic(roof, "r06_c2_pmc.json")
         if (n_total, nq, world) == (1_000_000, 256, 1):
             workload = "C2: brute-force cosine top-%d, 1M x 128 fp32 synthetic DB, batch=256 queries, 1 MI355X" % k
         elif world == 1 and args.shape == "c4":
@@ -1257,10 +1260,10 @@ def main():
                                         "(a projection: no multi-GPU node was available to this build)",
                                 "roofline": roofline(C4_NQ, C4_ROWS_PER_GPU, k, sc, ms4)}
             if k == 10:
-                attach_committed_traffic(line["c4_shard"]["roofline"], "r05_c4_pmc.json")
+                attach_committed_traffic(line["c4_shard"]["roofline"], "r06_c4_pmc.json")
             log("c4_shard: %.1f ms per 4096-query batch = %.0f q/s (fp32 scan %.1f ms = %.1f%% of fp32 MFMA peak)" % (ms4, C4_NQ / ms4 * 1e3, sc, line["c4_shard"]["roofline"]["frac"] * 100))
             if use_pf:
-                line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r05_pf_c4_pmc.json" if k == 10 else None)
+                line["c4_shard"]["prefiltered"] = pf_block(big, r4, 2, 1, prep_s=0.0, pmc="r06_pf_c4_pmc.json" if k == 10 else None)
                 p4 = line["c4_shard"]["prefiltered"]
                 log("c4_shard prefiltered: %.1f ms per batch = %.0f q/s, scan %.1f ms, identical: %s" % (p4["ms_per_step"], p4["queries_per_s"], p4["roofline"]["kernel_ms"], p4["identical_to_fp32"]))
             # the HBM-bound regime on the same 23.4 GB shard: reuse its rows

@@ -1462,7 +1462,10 @@ int pf_run(int stages, const float *db, const void *image, int format, int64_t n
         // inside its own launch -- the last workgroup of the query group, as ms_ip_topk does for such batches -- so that ONE gated launch
         // follows the re-scoring instead of two (each costs ~5 us even when it returns at once).  More queries: the last workgroup would
         // merge them one after the other (4.4 us each) while 255 others have finished; the merge launch stays.
-        const bool fuse_exact = nq <= fused_merge_setting() && L.exact_P_max <= 256 && (size_t)px.k_pass * L.exact_P_max <= 4224;
+        // (up to 8 queries whatever ms_ip_topk's own threshold is: the serial merge only runs for queries that were flagged -- rare -- while the
+        //  second launch costs every call; MS_PF_FUSE_EXACT_MAX_NQ overrides)
+        static const int fuse_max = [] { const char *e = getenv("MS_PF_FUSE_EXACT_MAX_NQ"); return e ? atoi(e) : 8; }();
+        const bool fuse_exact = nq <= fuse_max && L.exact_P_max <= 256 && (size_t)px.k_pass * L.exact_P_max <= 4224;
         if (fuse_exact) {
             sx.fin_s = out_scores; sx.fin_i = out_idx; sx.fin_row_offset = row_offset; sx.fin_stride = k; sx.fin_qmap = qmap;
             sx.ticket = reinterpret_cast<uint32_t *>(blk);

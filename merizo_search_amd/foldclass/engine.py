@@ -232,7 +232,7 @@ class HipEngine:
 
     # -- database residency ----------------------------------------------------------
     STAGE_ROWS = 1 << 19          # 256 MiB pinned staging buffers
-    COPY_THREADS = int(os.environ.get("MERIZO_COPY_THREADS", "0")) or min(32, os.cpu_count() or 8)
+    COPY_THREADS = int(os.environ.get("MERIZO_COPY_THREADS", "0")) or min(64, os.cpu_count() or 8)      # (64: 44-48 GB/s streamed on a 128-core host against 39-43 with 32 or 96: profiles/r06_streamed_copy_threads.log)
     # host threads filling a staging buffer (pread / numpy release the GIL while they copy)
 
     @staticmethod
@@ -264,7 +264,7 @@ class HipEngine:
             fd = os.open(fname, os.O_RDONLY)
             try:
                 flat = memoryview(dst.reshape(-1).view(np.uint8))
-                step = max(1 << 22, (nbytes + self.COPY_THREADS - 1) // self.COPY_THREADS)
+                step = max(1 << 21, (nbytes + self.COPY_THREADS - 1) // self.COPY_THREADS)
                 step = (step + 4095) // 4096 * 4096
 
                 def read(a):

@@ -536,7 +536,7 @@ def test_few_queries_take_the_fp16_image_scan_on_large_databases(nq, k, image, t
 @pytest.mark.parametrize("image", ["f16x2", "f16x1"])
 @pytest.mark.parametrize("nq,k,flag", [(1, 10, 1), (3, 10, 3), (8, 5, 4), (8, 16, 8), (9, 10, 9)])
 def test_few_flagged_queries_merge_inside_the_gated_exact_scan(nq, k, flag, image, torch_gpu):
-    """Round 6: for a handful of queries (<= the fused-merge threshold: 2 in production, 8 in this suite) over the fp16 image of a large
+    """Round 6: for a handful of queries (<= 8: MS_PF_FUSE_EXACT_MAX_NQ) over the fp16 image of a large
     database the exact pass behind the prefilter is ONE gated launch -- its last workgroup merges the flagged queries' lists and scatters
     them into their output rows -- instead of a scan and a merge launch.  `flag` of the nq queries own a family of 60 rows within ~1e-6 of
     each other (no proof possible: exactly they take the exact pass); 9 queries: the two-launch form.  Indices and score bits == the oracle,

@@ -980,8 +980,13 @@ def collective_preflight(torch, dist, ops, sharded, dev, world, backend, same_de
     torch.cuda.synchronize()
     assert int(mi_[0, 0]) == 3 * (world - 1) and float(ms_[0, 0]) == 2.0 + 100.0 * (world - 1), "exchange + merge pre-flight returned a wrong list"
     bus = ops.device_pci_bus_id(dev)
-    ids = [None] * world
-    dist.all_gather_object(ids, "%s|%s" % (os.uname().nodename, bus))
+    # (a fixed-size byte tensor on the device, gathered like the result blocks: no pickling, the same collective on either backend)
+    tag = ("%s|%s" % (os.uname().nodename, bus)).encode()[:96].ljust(96, b"\0")
+    mine = torch.tensor(list(tag), dtype=torch.uint8, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    torch.cuda.synchronize()
+    ids = [bytes(p_.cpu().tolist()).rstrip(b"\0").decode(errors="replace") for p_ in parts]
     _disarm_deadline()
     distinct = len(set(ids))
     rccl = None

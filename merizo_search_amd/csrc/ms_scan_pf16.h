@@ -38,6 +38,10 @@ constexpr uint32_t MS_PF16_MAGIC = 0x3631464du;       // "MF16"
 #ifndef MS_PF16_SHADOW
 #define MS_PF16_SHADOW 0
 #endif
+// Ablation builds (WRONG results; tools/pf_scan_only.py): what does each part of the steady stage cost?
+//   MS_PF16_ABL_NOMFMA  no matrix instructions (the accumulators are kept alive through an empty asm)
+//   MS_PF16_ABL_NOFILTER  no lane maxima / threshold compare (the rare path is never taken)
+//   MS_PF16_ABL_NODMA  no LDS-DMA pieces after the prologue (stale tiles; publication and waits unchanged)
 #ifdef MS_PF16_HALF_LDS          // (diagnostic build, WRONG results: only half of a tile's fragments are read from LDS -- what do the LDS reads cost?)
 #define MS_PF16_SECOND_READ(B)
 #else
@@ -60,6 +64,10 @@ constexpr uint32_t MS_PF16_MAGIC = 0x3631464du;       // "MF16"
 #ifndef MS_PF16_HIST_PERIOD
 #define MS_PF16_HIST_PERIOD MS_HIST_PERIOD     // tiles between two looks at the shared bound in this kernel (8 needs MS_PF2_HIST_AREAS = 8)
 #endif
+#ifndef MS_PF16_LEAD_LOAD
+#define MS_PF16_LEAD_LOAD 0        // 1: eight-wave workgroups, only waves 0-3 issue the LDS-DMA pieces -- measured: no change on five shapes
+                                   // (profiles/r06_pf16_lead_load_ab.log); 0 (default): every wave two pieces, as in rounds 4-5
+#endif
 #ifndef MS_PF16_VISIT2
 #define MS_PF16_VISIT2 1           // the rare path as straight-line predicated code (0: the ballot-and-select-tree form of rounds 4-5)
 #endif
@@ -74,7 +82,11 @@ template <int KL, int NW, bool SAMPLE, bool MASK, int NQP>
 __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const ScanParams p) {
     static_assert(NQP == 1 || NQP == 2, "query parts");
     static_assert(NW == 4 || NW == 8, "one or two waves per SIMD");
-    constexpr int PPW = 16 / NW;                       // LDS-DMA pieces of a tile per wave
+    // Round 6 experiment (MS_PF16_LEAD_LOAD=1, not the default: no gain): with eight waves only the FOUR OLDER ones (w < 4: they win the matrix pipe, run ahead and wait ~500 cycles per
+    // tile for the others) issue the LDS-DMA pieces, four each; the younger four -- the critical path -- issue none and only vouch for
+    // their progress at the arrival counters.  The requests also leave earlier (the leaders are up to two tiles ahead).
+    constexpr int LW = (NW == 8 && MS_PF16_LEAD_LOAD) ? 4 : NW;      // waves that load
+    constexpr int PPW = 16 / LW;                       // LDS-DMA pieces of a tile per loading wave
 #ifdef MS_STAMP
     const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();
     unsigned long long tl_setup = 0, tl_first = 0, tl_loop = 0;
@@ -115,9 +127,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     const uint64_t img0 = (uint64_t)(uintptr_t)p.pf_image + (uint64_t)(row_begin >> 6) * 16384u + (uint32_t)(1024 * PPW) * (uint32_t)wave;
     // (cosine mode: EVERY wave issues one more piece per tile so that the counted waits are the same for all of them; only wave 0's
     //  -- the rows' lengths -- is read)
+#ifdef MS_PF16_ABL_NODMA
+    bool abl_prologue_done = false;
+#endif
     uint64_t it_sb = 0;            // base address and LDS destination of the tile being issued (uniform)
     uint32_t it_dst = 0;
+    const bool loads = wave < LW;                      // (uniform)
     auto issue_prep = [&](int t) __attribute__((always_inline)) {
+        if (!loads) return;
         const uint64_t b = img0 + (uint64_t)t * 16384u;
         const uint32_t b_lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)b);
         const uint32_t b_hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(b >> 32));
@@ -127,9 +144,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     auto issue_piece = [&](auto i_c) __attribute__((always_inline)) {
         constexpr int I = decltype(i_c)::value;
         if constexpr (I < PPW) {
+            if (!loads) return;
             // (uniform values that live across branches: say so again, or the "s" operands of the asm may be handed vector registers)
             const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane(it_dst);
             const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)it_sb), hi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(it_sb >> 32));
+#ifdef MS_PF16_ABL_NODMA
+            if (abl_prologue_done) { asm volatile("" :: "s"(d), "s"(lo), "s"(hi)); return; }
+#endif
 #ifdef MS_PF2_NT
             ms_glds_s16_nt<1024 * I>(d + 1024 * I, voff, ((uint64_t)hi << 32) | (uint64_t)lo);
 #else
@@ -139,6 +160,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     };
     auto issue_aux = [&](int t) __attribute__((always_inline)) {
         if constexpr (MASK) {
+            if (!loads) return;
             int64_t row = row_begin + (int64_t)t * 64 + lane;        // (64 rows per tile: one length per lane)
             if (row >= p.n) row = p.n - 1;
             const uint32_t dst = wave == 0 ? ring_lds + PF2_OFF_AUX + (uint32_t)(t % PF2_AUXR) * 256u
@@ -152,10 +174,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         issue_piece(std::integral_constant<int, 2>{}); issue_piece(std::integral_constant<int, 3>{});
         issue_aux(t);
     };
-    // own pieces of every tile but the youngest N issued have landed
+    // own pieces of every tile but the youngest N issued have landed (a wave that loads nothing has nothing to wait for)
     auto wait_own = [&](auto n_c) __attribute__((always_inline)) {
         constexpr int N = decltype(n_c)::value;
-        ms_pf2_vmcnt<(PPW + (MASK ? 1 : 0)) * N>();
+        if (loads) ms_pf2_vmcnt<(PPW + (MASK ? 1 : 0)) * N>();
+    };
+    // ... the same in front of the shared bound's staging area (its two pieces are this wave's own whether it loads tiles or not)
+    auto wait_own_hist = [&]() __attribute__((always_inline)) {
+        if (loads) ms_pf2_vmcnt<(PPW + (MASK ? 1 : 0)) * 2>(); else ms_pf2_vmcnt<0>();
     };
     // publication: this wave's pieces of tile t have landed -> one more arrival at the tile's counter
     const uint32_t arr_lds = ring_lds + PF2_OFF_CNT;
@@ -246,6 +272,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
     for (int t = 0; t < PF2_D; ++t)
         if (t < ntl) issue_tile(t);
 
+#ifdef MS_PF16_ABL_NODMA
+    abl_prologue_done = true;
+#endif
     if (!has_q) {
         // loading-only wave (the workgroup's last query tiles are padding): issue, publish, keep pace with the readers
         // (it waits for the same arrivals as a wave that computes: that is what keeps it from overwriting a slot in use)
@@ -547,8 +576,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
                 "v_max3_f32 %0, %0, %10, %11\n\tv_max3_f32 %0, %0, %12, %13\n\tv_max3_f32 %0, %0, %14, %15\n\tv_max_f32 %0, %0, %16"               \
                 : "=&v"(M) : "v"(PV[0]), "v"(PV[1]), "v"(PV[2]), "v"(PV[3]), "v"(PV[4]), "v"(PV[5]), "v"(PV[6]), "v"(PV[7]), "v"(PV[8]), "v"(PV[9]), \
                   "v"(PV[10]), "v"(PV[11]), "v"(PV[12]), "v"(PV[13]), "v"(PV[14]), "v"(PV[15]))
+#ifdef MS_PF16_ABL_NOFILTER
+            asm volatile("" : "+v"(pv0), "+v"(pv1));
+            mx = -INFINITY; mx1 = -INFINITY;
+#else
             MS_PF16_MAX(mx, pv0);
             MS_PF16_MAX(mx1, pv1);
+#endif
 #undef MS_PF16_MAX
             // (each half tile is visited only if one of ITS scores passes: a visit costs ~900 cycles per half, candidate or not)
             const bool hit0 = __ballot(mx > tau_s) != 0, hit1 = __ballot(mx1 > tau_s) != 0;
@@ -592,11 +626,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         // 8 cycles next to a matrix instruction and 60-185 in a burst.
         const f32x4 *src = frag_base(t + 1);
         const bool issuing = STEADY || t + PF2_D < ntl;         // (uniform)
+#ifdef MS_PF16_ABL_NOMFMA
+#define MS_PF16_MFMA(ACC, F, Q) asm volatile("" : "+v"(ACC) : "v"(F), "v"(Q));
+#else
+#define MS_PF16_MFMA(ACC, F, Q) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(F, Q, ACC, 0, 0, 0);
+#endif
 #define MS_PF2_BLOCK(B)                                                                                               \
         {                                                                                                             \
             const f16x8 f0 = __builtin_bit_cast(f16x8, fr[2 * (B)]), f1 = __builtin_bit_cast(f16x8, fr[2 * (B) + 1]);   \
-            out0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, qh[B], out0, 0, 0, 0);                                  \
-            out1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, qh[B], out1, 0, 0, 0);                                  \
+            MS_PF16_MFMA(out0, f0, qh[B])                                                                             \
+            MS_PF16_MFMA(out1, f1, qh[B])                                                                             \
             if constexpr (NQP == 2) {                                                                                 \
                 out0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, ql[B], out0, 0, 0, 0);                              \
                 out1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, ql[B], out1, 0, 0, 0);                              \
@@ -686,7 +725,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             if (phase == read_phase && t >= 2) {
                 PF2_T0();
                 // the two stages since then issued two tiles' pieces behind the counters' (near the end of a stream: fewer -- drain)
-                if (t - 1 + PF2_D < ntl) wait_own(std::integral_constant<int, 2>{}); else ms_pf2_vmcnt<0>();
+                if (t - 1 + PF2_D < ntl) wait_own_hist(); else ms_pf2_vmcnt<0>();
                 const ms_u32x4 *hp = reinterpret_cast<const ms_u32x4 *>(smem + PF2_OFF_HIST + hist_area * 2048 + r * 64);
                 const ms_u32x4 c0 = hp[0], c1 = hp[1], c2 = hp[2], c3 = hp[3];
                 const uint32_t c[16] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x, c3.y, c3.z, c3.w};

@@ -1041,6 +1041,10 @@ int run_prepass(const ScanPlan &pl, ScanParams *sp, int nq, char *ws, hipStream_
         const int cap = 512 / pl.P > enough ? 512 / pl.P : enough;
         if (ranks > cap) ranks = cap > 1 ? cap : 1;
     }
+    {   // diagnostics / tuning: MS_BOUND_RANKS caps how many entries per sample list the bound selection reads (fewer = a cheaper, weaker bound)
+        static const int cap_env = [] { const char *e = getenv("MS_BOUND_RANKS"); return e ? atoi(e) : 0; }();
+        if (cap_env > 0 && cap_env < ranks && (int64_t)cap_env * pl.P >= 4 * (int64_t)s0.k) ranks = cap_env;
+    }
     const int vpl = (ranks * pl.P + 63) / 64;
     const size_t sm_stride = s0.list_sm ? (size_t)pl.nq_pad * s0.k : 0;       // (the image scans, and the loader-wave kernel where its merge allows, write stream-major lists)
     if (vpl > 32 && sm_stride != 0) MS_FAIL(MS_ERR_RANGE, "internal: %d sample lists of the image scan exceed the bound selection", pl.P);

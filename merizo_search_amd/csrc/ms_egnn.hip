@@ -355,6 +355,9 @@ constexpr int EDGE_LDS = 2 * W_STAGE_F4 * 16;                     // two ring sl
 // The default stays round 4's form: two workgroups of four waves per CU, a ring of three slots each, a barrier per block.
 constexpr bool EGNN_W8 = MS_EGNN_W8 != 0;
 constexpr int EDGE_RING_SPLIT = EGNN_W8 ? 6 : 3;
+#ifndef MS_EGNN_DYNPRIO
+#define MS_EGNN_DYNPRIO 0
+#endif
 constexpr int EDGE_LDS_SPLIT = EDGE_RING_SPLIT * W2S_BLOCK_BYTES; // split form: slots of one k block (24 KiB) each: 144 KiB (72 KiB with 3)
 
 // SPLIT (round 4): the same GEMM on the bf16 matrix instruction -- v_mfma_f32_32x32x16_bf16 at 16 x the rate of the fp32 one --
@@ -541,6 +544,11 @@ __global__ __launch_bounds__((SPLIT && EGNN_W8) ? 512 : 256, 2) void ms_egnn_edg
             }
             ah = __builtin_bit_cast(bf16x8_e, hi); am = __builtin_bit_cast(bf16x8_e, mid); al = __builtin_bit_cast(bf16x8_e, lo);
         };
+#if MS_EGNN_DYNPRIO
+        uint32_t *prio_cnt = reinterpret_cast<uint32_t *>(smem + EDGE_LDS_SPLIT);      // (64 bytes behind the ring)
+        if (tid == 0) *prio_cnt = 0u;
+        __syncthreads();
+#endif
         // prologue: the first blocks of the ring are requested before anything else (8 waves: four blocks ahead; 4 waves: two)
         constexpr int AHEAD = W8 ? 4 : 2;
 #pragma unroll
@@ -560,6 +568,17 @@ __global__ __launch_bounds__((SPLIT && EGNN_W8) ? 512 : 256, 2) void ms_egnn_edg
             // both (they were requested four blocks ahead; the vmcnt(0) in the middle of block 2p - 1 covers everything requested up to
             // block 2p - 2, i.e. blocks <= 2p + 2) and is done with the pair before; during block b the pieces of block b + 4 go to
             // slot (b + 4) % 6 = (b - 2) % 6, a slot of the PREVIOUS pair, which nobody reads any more.
+#if MS_EGNN_DYNPRIO
+            if constexpr (!W8) {
+                // Round 6 experiment: the wave that arrives LAST at a block's barrier -- the one its workgroup waited for -- takes the higher
+                // issue priority for the next block's chain, the others the lower one (arrival order from a counter in LDS: 4 adds per block)
+                uint32_t ord_ = 0;
+                if (lane == 0) ord_ = __hip_atomic_fetch_add(prio_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ord_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)ord_) & 3u;
+                __syncthreads();
+                if (ord_ == 3u) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+            } else
+#endif
             if (!W8 || (b & 1) == 0) __syncthreads();
             EST(tB1)
             const u32x4_e *Sl = Sring + (b % EDGE_RING_SPLIT) * BLK_V + lane;
@@ -926,7 +945,7 @@ int ms_egnn_embed(const void *prepared, const float *pe, int pe_len, const float
     MS_LAUNCH_CHECK("ms_egnn_init_nodes_kernel");
     // the edge GEMM: split-bf16 matrix instructions (default; fp32-grade results) or MS_EGNN_SPLIT=0: the fp32 ones
     static const int split_form = [] { const char *e = getenv("MS_EGNN_SPLIT"); return e ? atoi(e) : 1; }();
-    const size_t edge_lds = split_form ? (size_t)EDGE_LDS_SPLIT : (size_t)EDGE_LDS;
+    const size_t edge_lds = split_form ? (size_t)EDGE_LDS_SPLIT + (MS_EGNN_DYNPRIO ? 64 : 0) : (size_t)EDGE_LDS;
     if (split_form)
         MS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(ms_egnn_edge_kernel<true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)edge_lds));

@@ -998,10 +998,19 @@ def collective_preflight(torch, dist, ops, sharded, dev, world, backend, same_de
     info = {"backend": dist.get_backend(), "world": world, "distinct_devices": distinct, "pci_bus_ids": sorted(set(i.split("|", 1)[1] for i in ids)),
             "rccl_version": rccl, "same_device_selftest": bool(same_device), "exchange_us": None,
             "preflight": "8-byte all-reduce + PackedExchange round trip passed within %.0f s" % PREFLIGHT_DEADLINE_S}
-    if dist.get_backend() == "nccl" and distinct != world:
-        raise SystemExit("bench.py --gpus %d over RCCL: the %d ranks sit on %d distinct device(s) %s -- one GPU per rank is required "
-                         "(check HIP_VISIBLE_DEVICES / LOCAL_RANK)" % (world, world, distinct, info["pci_bus_ids"]))
+    refuse_shared_devices(dist.get_backend(), world, ids)
     return info
+
+
+def refuse_shared_devices(backend, world, ids):
+    """An RCCL run must have one DISTINCT device per rank (`ids`: one "host|pci bus id" string per rank): anything else is a mis-set
+    HIP_VISIBLE_DEVICES / LOCAL_RANK that would show up as a hang, or as N ranks timing one GPU and calling it scaling.  gloo runs (the
+    one-GPU self-tests, MS_BENCH_SAME_DEVICE=1) may share a device: their line says so (`distinct_devices`, `same_device_selftest`)."""
+    distinct = len(set(ids))
+    if backend == "nccl" and distinct != world:
+        raise SystemExit("bench.py --gpus %d over RCCL: the %d ranks sit on %d distinct device(s) %s -- one GPU per rank is required "
+                         "(check HIP_VISIBLE_DEVICES / LOCAL_RANK)" % (world, world, distinct, sorted(set(ids))))
+    return distinct
 
 
 def time_exchange(bench, reps=20):

@@ -81,6 +81,19 @@ def test_line_without_optional_blocks():
                                   "same_device_selftest": False}
 
 
+def test_rccl_ranks_that_share_a_device_are_refused():
+    """Round 6: an N > 1 run over RCCL whose ranks do not sit on N distinct devices fails before anything is timed; gloo
+    self-tests on one device pass (and their line says `distinct_devices: 1`)."""
+    import pytest
+    eight = ["node|0000:%02x:00.0" % (5 + 16 * i) for i in range(8)]
+    assert bench.refuse_shared_devices("nccl", 8, eight) == 8
+    assert bench.refuse_shared_devices("gloo", 8, ["node|0000:05:00.0"] * 8) == 1
+    with pytest.raises(SystemExit, match="distinct device"):
+        bench.refuse_shared_devices("nccl", 8, eight[:7] + eight[:1])
+    with pytest.raises(SystemExit, match="one GPU per rank"):
+        bench.refuse_shared_devices("nccl", 2, ["node|0000:05:00.0"] * 2)
+
+
 def test_line_carries_the_streamed_headline():
     """Round 6: the `streamed` block (host memmap over PCIe) puts its two headline numbers under `more`."""
     doc = _doc()

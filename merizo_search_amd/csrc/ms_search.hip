@@ -216,7 +216,11 @@ __global__ __launch_bounds__(64) void ms_head_merge_kernel(const float *part_s, 
 __device__ __forceinline__ void ms_block_merge_body(char *smem, const float *part_s, const uint32_t *part_i, int P, int k,
                                                     int64_t row_offset, float *out_s, int64_t *out_i,
                                                     int out_stride, int out_col0, float *ub_s, uint32_t *ub_i,
-                                                    const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride) {
+                                                    const ScanDevPlan *dp, const int *qmap, int sparse, size_t sm_stride,
+                                                    uint2 *keep = nullptr) {
+    // keep (round 6; the fused merge + re-scoring launch): the k merged entries are ALSO left in LDS -- keep[rank] = {score bits, row or
+    // MS_IDX_NONE}, keep[64].x = 1 when they are all there -- so that the re-scoring behind the merge does not read back through L2 what
+    // this workgroup has just written (one round trip of ~1.5 us per call)
     int q = blockIdx.x;
     if (dp != nullptr) {
         if (q >= dp->nq) return;
@@ -273,13 +277,16 @@ __device__ __forceinline__ void ms_block_merge_body(char *smem, const float *par
                     const size_t o = (size_t)q_out * out_stride + out_col0 + rank;
                     out_s[o] = __uint_as_float(v.x);
                     out_i[o] = row_offset + (int64_t)v.y;
+                    if (keep != nullptr) keep[rank] = v;
                 }
             }
             if (tid < k && tid >= n) {
                 const size_t o = (size_t)q_out * out_stride + out_col0 + tid;
                 out_s[o] = -INFINITY;
                 out_i[o] = -1;
+                if (keep != nullptr) keep[tid] = make_uint2(__float_as_uint(-INFINITY), MS_IDX_NONE);
             }
+            if (keep != nullptr && tid == 0) keep[64].x = 1u;
             return;
         }
         __syncthreads();            // (the pool is abandoned: the scratch area is the general merge's from here on)
@@ -307,7 +314,12 @@ __device__ __forceinline__ void ms_block_merge_body(char *smem, const float *par
     if (fin == nullptr) {        // (uniform across the workgroup)
         if (tid < 64)       // (`ent` is staged already: the wave reads nothing at part_s / part_i, and q only names the output row)
             ms_head_merge_wave<4, true>(ent, part_s, part_i, P, k, row_offset, out_s, out_i, out_stride, out_col0, ub_s, ub_i, q_out, tid);
+        if (keep != nullptr && tid == 0) keep[64].x = 0u;      // (this rare form writes the global lists only: the re-scoring reads them back)
         return;
+    }
+    if (keep != nullptr) {
+        if (tid < k) keep[tid] = fin[tid];
+        if (tid == 0) keep[64].x = 1u;
     }
     if (tid < k) {
         const uint2 v = fin[tid];
@@ -429,7 +441,7 @@ struct PfRescore {
 };
 // Every thread of the workgroup calls it (barriers inside); the first wave does the work.  `coherent`: the candidate lists were
 // written by THIS workgroup a moment ago (the fused merge + re-scoring launch): read them past the L1.
-__device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int tid, bool coherent) {
+__device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int tid, bool coherent, const uint2 *keep = nullptr) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -469,7 +481,12 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
         qnorm = sqrtf(qq) * 1.001f;
         const int64_t *aq = a.ai + (size_t)q * kp;
         const float *sq = a.as + (size_t)q * kp;
-        if (coherent) {
+        if (keep != nullptr && keep[64].x != 0u) {          // (uniform) the candidates are still in LDS
+            const uint2 mine = keep[lane < kp ? lane : 0], last = keep[kp - 1];
+            row = (lane < kp && mine.y != MS_IDX_NONE) ? (int64_t)mine.y : -1;
+            full = last.y != MS_IDX_NONE;
+            a_last = __uint_as_float(last.x);
+        } else if (coherent) {
             row = lane < kp ? __hip_atomic_load(aq + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
             full = __hip_atomic_load(aq + kp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
             a_last = __hip_atomic_load(sq + kp - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -567,10 +584,11 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
 __global__ __launch_bounds__(256) void ms_merge_rescore_kernel(const float *part_s, const uint32_t *part_i, int P, float *as, int64_t *ai,
                                                                size_t sm_stride, const PfRescore a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    ms_block_merge_body(smem, part_s, part_i, P, a.kp, 0, as, ai, a.kp, 0, nullptr, nullptr, nullptr, nullptr, 1, sm_stride);
+    __shared__ uint2 keep[65];          // the kp <= 64 merged candidates + [64].x: are they all here?
+    ms_block_merge_body(smem, part_s, part_i, P, a.kp, 0, as, ai, a.kp, 0, nullptr, nullptr, nullptr, nullptr, 1, sm_stride, keep);
     __threadfence_block();
     __syncthreads();
-    ms_rescore_body(a, (int)blockIdx.x, (int)threadIdx.x, true);
+    ms_rescore_body(a, (int)blockIdx.x, (int)threadIdx.x, true, keep);
 }
 
 // ------------------------------------------------------------------ public k-way merge -

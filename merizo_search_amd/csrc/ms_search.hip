@@ -469,7 +469,19 @@ struct PfRescore {
 };
 // Every thread of the workgroup calls it (barriers inside); the first wave does the work.  `coherent`: the candidate lists were
 // written by THIS workgroup a moment ago (the fused merge + re-scoring launch): read them past the L1.
-__device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int tid, bool coherent, const uint2 *keep = nullptr) {
+// The query of a re-scoring workgroup, requested early (round 6: the fused launch asks for it BEFORE it merges the candidate lists, so that its
+// round trip runs under the merge's own loads): this lane's float2 of the raw query, or its two floats of the prepared one
+struct PfQueryPre { float x, y; };
+__device__ __forceinline__ PfQueryPre ms_rescore_query_load(const PfRescore &a, int q, int tid) {
+    PfQueryPre r{0.0f, 0.0f};
+    if (tid < 64) {
+        if (a.q_eps > 0.0f) { const float2 v = *(reinterpret_cast<const float2 *>(a.qn + (size_t)q * MS_DIM) + tid); r.x = v.x; r.y = v.y; }
+        else { r.x = a.qn[(size_t)q * MS_DIM + tid]; r.y = a.qn[(size_t)q * MS_DIM + 64 + tid]; }
+    }
+    return r;
+}
+__device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int tid, bool coherent, const uint2 *keep = nullptr,
+                                                const PfQueryPre *pre = nullptr) {
     __shared__ float qs[128];
     __shared__ float cs[64];
     __shared__ uint32_t ci[64];
@@ -485,7 +497,8 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
             // arithmetic of ms_normalize_rows_kernel -- float2 per lane, the same butterfly sum, sqrt, max, divide: the same bits -- which
             // is what the exact scores below (and the exact pass's copy of the query) are made of; the image scan in front of this launch
             // normalised the same query approximately, which is all its error bound asks for (ms_scan_pf16.h)
-            float2 v = *(reinterpret_cast<const float2 *>(a.qn + (size_t)q * MS_DIM) + lane);
+            const PfQueryPre ld = pre != nullptr ? *pre : ms_rescore_query_load(a, q, tid);
+            float2 v = make_float2(ld.x, ld.y);
             const float ss = wave_sum(v.x * v.x + v.y * v.y);
             const float nrm = fmaxf(sqrtf(ss), a.q_eps);
             v.x = v.x / nrm;
@@ -493,8 +506,9 @@ __device__ __forceinline__ void ms_rescore_body(const PfRescore &a, int q, int t
             qs[2 * lane] = v.x;
             qs[2 * lane + 1] = v.y;
         } else {
-            qs[lane] = a.qn[(size_t)q * MS_DIM + lane];
-            qs[64 + lane] = a.qn[(size_t)q * MS_DIM + 64 + lane];
+            const PfQueryPre ld = pre != nullptr ? *pre : ms_rescore_query_load(a, q, tid);
+            qs[lane] = ld.x;
+            qs[64 + lane] = ld.y;
         }
         if (lane == 0) kth = -INFINITY;
     }
@@ -613,10 +627,11 @@ __global__ __launch_bounds__(256) void ms_merge_rescore_kernel(const float *part
                                                                size_t sm_stride, const PfRescore a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ uint2 keep[65];          // the kp <= 64 merged candidates + [64].x: are they all here?
+    const PfQueryPre pre = ms_rescore_query_load(a, (int)blockIdx.x, (int)threadIdx.x);
     ms_block_merge_body(smem, part_s, part_i, P, a.kp, 0, as, ai, a.kp, 0, nullptr, nullptr, nullptr, nullptr, 1, sm_stride, keep);
     __threadfence_block();
     __syncthreads();
-    ms_rescore_body(a, (int)blockIdx.x, (int)threadIdx.x, true, keep);
+    ms_rescore_body(a, (int)blockIdx.x, (int)threadIdx.x, true, keep, &pre);
 }
 
 // ------------------------------------------------------------------ public k-way merge -

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
         if (sm_stride == 0) v[i] = idx < count ? ps[idx] : -INFINITY;
         else v[i] = idx < count ? part_s[(size_t)(idx % P) * sm_stride + (size_t)q * k + idx / P] : -INFINITY;
     }
-    float kth = -INFINITY, top = -INFINITY;
+    float kth = -INFINITY, top = -INFINITY, second = -INFINITY, third = -INFINITY;        // (second, third: with multiplicity)
     // wave maximum: 4 DPP steps inside each row of 16 lanes, then the 4 row results through SGPRs
 #define MS_DPP_FMAX(CTRL) m = fmaxf(m, __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(m), CTRL, 0xF, 0xF, false)));
     if constexpr (VPL <= 8) {
@@ -380,6 +380,8 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
             m = fmaxf(fmaxf(ms_readlane_f(m, 0), ms_readlane_f(m, 16)), fmaxf(ms_readlane_f(m, 32), ms_readlane_f(m, 48)));
             if (!(m > -INFINITY)) { kth = -INFINITY; break; }             // fewer than k values: no bound
             if (round == 0) top = m;
+            if (round == 1) second = m;
+            if (round == 2) third = m;
             kth = m;
             const int win = __builtin_ctzll(__ballot(v[0] == m));        // (some lane's head IS the maximum)
             if (lane == win) {
@@ -402,6 +404,9 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
         int c = 0;
 #pragma unroll
         for (int i = 0; i < VPL; ++i) c += __popcll(__ballot(v[i] == m));
+        const int seen = k - remaining;                               // values above m so far
+        if (seen < 2 && seen + c >= 2) second = m;
+        if (seen < 3 && seen + c >= 3) third = m;
         if (c >= remaining) { kth = m; break; }
         remaining -= c;
         cur = m;
@@ -412,10 +417,24 @@ __global__ __launch_bounds__(64) void ms_sample_bound_kernel(const float *part_s
     // Score buckets of the full pass's shared bound (ScanHist): the k-th best of the whole shard sits near the sample's BEST
     // score (the sample is a few percent of the rows), so 16 buckets of (best - k-th) / 12 from the k-th up cover the range
     // the bound moves through; the last bucket is open-ended.  No usable spread: step 0 = no histogram for this query.
+    // Round 6: "best - k-th" is taken from the SLOPE of the sample's tail, not from its single best score.  Scores of rank r in a tail fall
+    // like kth + b ln(k / r); b from rank 1, 2 and 3 each, the MEDIAN of the three.  On a smooth tail the three agree and the buckets are
+    // the ones above; a sampled row that is no part of the tail -- a near-duplicate of the query, a close homologue: cosine 0.97 over a
+    // tail that ends at 0.35 -- used to stretch the 16 buckets over the whole gap, the bound of that query then never rose, and its ~1,200
+    // rows above the sample bound (not ~60) all went through the rare path, the merge and the re-scoring: the bench's database plants three
+    // such rows per query, ~6 of 256 queries caught one in the sample, and the C2 step cost 141 us instead of 130
+    // (profiles/r06_hist_step_ab.log).
     if (hist != nullptr) {
         if (lane < 16) hist[(size_t)q * 16 + lane] = 0u;
         if (lane == 0) {
-            float step = (kth > -INFINITY && top > kth) ? (top - kth) * (1.0f / 12.0f) : 0.0f;
+            float spread = (kth > -INFINITY && top > kth) ? top - kth : 0.0f;
+            if (spread > 0.0f && k >= 4) {
+                const float lk = __logf((float)k);
+                const float b1 = (top - kth) / lk, b2 = (second - kth) / (lk - 0.6931472f), b3 = (third - kth) / (lk - 1.0986123f);
+                const float bm = fmaxf(fminf(b1, b2), fminf(fmaxf(b1, b2), b3));                 // median
+                if (bm > 0.0f && bm < INFINITY) spread = bm * lk;
+            }
+            float step = spread * (1.0f / 12.0f);
             if (!(step > 0.0f) || !(step < INFINITY) || !(1.0f / step < INFINITY)) step = 0.0f;
             hstep[q] = step;
         }

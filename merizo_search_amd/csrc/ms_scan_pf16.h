@@ -54,6 +54,9 @@ constexpr uint32_t MS_PF16_MAGIC = 0x3631464du;       // "MF16"
 #ifndef MS_PF16_DYNPRIO
 #define MS_PF16_DYNPRIO 1
 #endif
+#ifndef MS_PF16_ILV
+#define MS_PF16_ILV 0
+#endif
 #if MS_PF16_DYNPRIO
 #define MS_PF16_PRIO_BEHIND "s_setprio 2\n\t"
 #define MS_PF16_PRIO_AHEAD "s_setprio 0\n\t"
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
 #endif
     uint64_t it_sb = 0;            // base address and LDS destination of the tile being issued (uniform)
     uint32_t it_dst = 0;
-    const bool loads = wave < LW;                      // (uniform)
+    const bool loads = (LW == NW) ? true : (wave < LW);      // (uniform; a constant when every wave loads: no branch around the pieces)
     auto issue_prep = [&](int t) __attribute__((always_inline)) {
         if (!loads) return;
         const uint64_t b = img0 + (uint64_t)t * 16384u;
@@ -644,6 +647,46 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
             fr[2 * (B)] = src[64 * (2 * (B))];                                                                        \
             MS_PF16_SECOND_READ(B)                                                                                    \
         }
+#if MS_PF16_ILV
+        // (MS_PF16_ILV: matrix instruction, the read that replaces ITS operand, matrix instruction, read -- each read issues in the 32-cycle
+        //  shadow of the instruction in front of it, and only "everything else" follows the second one)
+#undef MS_PF2_BLOCK
+#define MS_PF2_BLOCK(B)                                                                                               \
+        {                                                                                                             \
+            const f16x8 f0 = __builtin_bit_cast(f16x8, fr[2 * (B)]), f1 = __builtin_bit_cast(f16x8, fr[2 * (B) + 1]);   \
+            MS_PF16_MFMA(out0, f0, qh[B])                                                                             \
+            if constexpr (NQP == 2) out0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f0, ql[B], out0, 0, 0, 0);          \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            fr[2 * (B)] = src[64 * (2 * (B))];                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            MS_PF16_MFMA(out1, f1, qh[B])                                                                             \
+            if constexpr (NQP == 2) out1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(f1, ql[B], out1, 0, 0, 0);          \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            MS_PF16_SECOND_READ(B)                                                                                    \
+        }
+#endif
+#ifdef MS_PF16_ABL_1616
+        // (diagnostic build, WRONG results: the same operands through 32 v_mfma_f32_16x16x32_f16 on eight 4-register accumulators -- what would the
+        //  other matrix shape's instruction mix run at?)
+        typedef float f32x4_ __attribute__((ext_vector_type(4)));
+        f32x4_ oa[4], ob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { oa[i] = f32x4_{0.0f, 0.0f, 0.0f, 0.0f}; ob[i] = f32x4_{0.0f, 0.0f, 0.0f, 0.0f}; }
+#undef MS_PF2_BLOCK
+#define MS_PF2_BLOCK(B)                                                                                               \
+        {                                                                                                             \
+            const f16x8 f0 = __builtin_bit_cast(f16x8, fr[2 * (B)]), f1 = __builtin_bit_cast(f16x8, fr[2 * (B) + 1]);   \
+            oa[(B) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, qh[B], oa[(B) & 3], 0, 0, 0);                    \
+            ob[(B) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, qh[B], ob[(B) & 3], 0, 0, 0);                    \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            fr[2 * (B)] = src[64 * (2 * (B))];                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            oa[((B) + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f0, qh[((B) + 1) & 7], oa[((B) + 2) & 3], 0, 0, 0); \
+            ob[((B) + 2) & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(f1, qh[((B) + 1) & 7], ob[((B) + 2) & 3], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                                        \
+            MS_PF16_SECOND_READ(B)                                                                                    \
+        }
+#endif
         MS_PF2_BLOCK(0)
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(1)
@@ -671,6 +714,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         __builtin_amdgcn_sched_barrier(0);
         MS_PF2_BLOCK(7)
 #undef MS_PF2_BLOCK
+#ifdef MS_PF16_ABL_1616
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { out0[i] = oa[i >> 2][i & 3]; out1[i] = ob[i >> 2][i & 3]; }
+#endif
 #ifdef MS_STAMP
         asm volatile("s_nop 0" : "+v"(out0), "+v"(out1));
 #endif

@@ -1,12 +1,12 @@
 """The prefilter scan over each image arithmetic (f16x2, f16x1, bf16x3) and without an image: a few shapes against the fp32 scan, with
 timings.  usage: python tools/pf2_try.py [n,nq,k ...]"""
-import sys, time
+import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
 from merizo_search_amd import ops
 from merizo_search_amd.foldclass import synthetic as syn
 
-def run(n, nq, k, reps=20):
+def run(n, nq, k, reps=int(os.environ.get("MS_TRY_REPS", "20"))):
     d = syn.device_database(n, 0, seed=0, device="cuda", normalize=True)
     g = torch.Generator(device="cuda"); g.manual_seed(1)
     q = torch.randn((nq, 128), generator=g, device="cuda"); q = q / q.norm(dim=1, keepdim=True)
@@ -15,7 +15,10 @@ def run(n, nq, k, reps=20):
     ws = torch.empty_like(ops.PrefilterWorkspace(d.device).get(n, nq, k))
     s0, i0 = ops.ip_topk(d, q, k)
     res = {}
+    only = [f for f in os.environ.get("MS_TRY_FORMATS", "").split(",") if f]          # e.g. MS_TRY_FORMATS=f16x1,f16x2
     for name, image in (("f16x2", img), ("f16x1", img.as_format(ops.PF_F16X1)), ("bf16x3", img3), ("regs", None)):
+        if only and name not in only:
+            continue
         s, i = ops.ip_topk_prefiltered(d, q, k, 1.0 + 1e-6, workspace=ws, image=image)
         torch.cuda.synchronize()
         ok = bool(torch.equal(i, i0) and torch.equal(s.view(torch.int32), s0.view(torch.int32)))

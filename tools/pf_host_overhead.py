@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from merizo_search_amd import ops
 from merizo_search_amd.foldclass import synthetic as syn

@@ -2,7 +2,7 @@
 one?  Per-stage HIP events for {bench db, plain db} x {bench queries, fresh queries}; profiles/r06_hist_step_ab.log holds the answer
 before and after the histogram's bucket width was taken from the slope of the sample's tail (ms_sample_bound_kernel)."""
 import sys, os, time
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from merizo_search_amd import ops

@@ -360,7 +360,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float c = fminf(fmaxf(x[j], -65504.0f), 65504.0f);
+#ifdef MS_PF16_ABL_BF16
+                const _Float16 hi16 = __builtin_bit_cast(_Float16, (__bf16)c);
+#elif defined(MS_PF16_ABL_F16R8)
+                const _Float16 hi16 = (_Float16)(float)(__bf16)c;
+#else
                 const _Float16 hi16 = (_Float16)c;                     // round to nearest even
+#endif
                 qh[b][j] = hi16;
                 if constexpr (NQP == 2) ql[b][j] = (_Float16)(c - (float)hi16);
             }
@@ -631,6 +637,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void ms_scan_pf16_kernel(const Sca
         const bool issuing = STEADY || t + PF2_D < ntl;         // (uniform)
 #ifdef MS_PF16_ABL_NOMFMA
 #define MS_PF16_MFMA(ACC, F, Q) asm volatile("" : "+v"(ACC) : "v"(F), "v"(Q));
+#elif defined(MS_PF16_ABL_BF16)
+// (diagnostic build, WRONG results: the same bits through the bf16 form of the instruction -- does the narrower multiplier hold a higher clock?)
+#define MS_PF16_MFMA(ACC, F, Q) ACC = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, F), __builtin_bit_cast(bf16x8, Q), ACC, 0, 0, 0);
 #else
 #define MS_PF16_MFMA(ACC, F, Q) ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(F, Q, ACC, 0, 0, 0);
 #endif

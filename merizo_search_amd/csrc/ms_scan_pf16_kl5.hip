@@ -46,7 +46,15 @@ __global__ __launch_bounds__(256) void ms_pf16_build_image_kernel(const float *d
             const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             f16x8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (_Float16)fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+            for (int j = 0; j < 8; ++j) {
+#ifdef MS_PF16_ABL_BF16
+                o[j] = __builtin_bit_cast(_Float16, (__bf16)fminf(fmaxf(v[j], -65504.0f), 65504.0f));      // (diagnostic build: a bf16 image in the same layout)
+#elif defined(MS_PF16_ABL_F16R8)
+                o[j] = (_Float16)(float)(__bf16)fminf(fmaxf(v[j], -65504.0f), 65504.0f);                   // (diagnostic build: fp16 values with 8 significant bits)
+#else
+                o[j] = (_Float16)fminf(fmaxf(v[j], -65504.0f), 65504.0f);
+#endif
+            }
             *reinterpret_cast<f16x8 *>(dst + 1024 * (2 * b + half)) = o;
         }
     }
